@@ -1,0 +1,98 @@
+"""In-tree build of libdcvc_amd.so (HIP kernels for gfx950 + host codec + C ABI).
+
+hipcc compiles every translation unit under dcvc_amd/csrc (``.hip`` = device + host,
+``.cpp`` = host only) into objects under dcvc_amd/csrc/_obj and links
+dcvc_amd/libdcvc_amd.so. No GPU is needed to build (hipcc cross-compiles gfx950).
+Incremental: an object is rebuilt when its source or any header is newer.
+
+Usage: python -m dcvc_amd.build [--force] [--verbose]
+"""
+import concurrent.futures
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(PKG, "libdcvc_amd.so")
+ARCH = "gfx950"
+
+COMMON = [
+    "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
+    # arithmetic policy: no fast-math, no implicit contraction - every fma is spelled fmaf()
+    # so that the CPU oracle can reproduce the device arithmetic bit for bit.
+    "-ffp-contract=off", "-fno-fast-math",
+    "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+]
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-munsafe-fp-atomics"]
+
+
+def _sources():
+    srcs = []
+    for pat in ("*.cpp", "*.hip", "*/*.cpp", "*/*.hip"):
+        srcs += glob.glob(os.path.join(CSRC, pat))
+    return sorted(s for s in srcs if os.sep + "_obj" + os.sep not in s)
+
+
+def _headers():
+    hs = glob.glob(os.path.join(ROOT, "include", "*.h"))
+    for pat in ("*.h", "*/*.h", "*.hpp", "*/*.hpp"):
+        hs += glob.glob(os.path.join(CSRC, pat))
+    return hs
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _compile(src, obj, verbose):
+    # ``.hip`` = anything that includes the HIP runtime (kernels and the host codec);
+    # ``.cpp`` = plain host C++ (the rANS coder), still compiled by hipcc's clang.
+    cmd = [_hipcc(), "-c"] + COMMON
+    if src.endswith(".hip"):
+        cmd += ["-x", "hip"] + HIP_FLAGS
+    cmd += ["-o", obj, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("compile failed: %s\n%s\n%s" % (src, res.stdout, res.stderr))
+    if verbose and res.stderr.strip():
+        print(res.stderr)
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    hdr_time = max([os.path.getmtime(h) for h in _headers()] + [0.0])
+    jobs = []
+    objs = []
+    for s in srcs:
+        rel = os.path.relpath(s, CSRC).replace(os.sep, "__")
+        o = os.path.join(OBJ, rel + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            jobs.append((s, o))
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(lambda a: _compile(a[0], a[1], verbose), jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + \
+              ["-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
