@@ -9,6 +9,7 @@ Usage: python -m dcvc_amd.build [--force] [--verbose]
 """
 import concurrent.futures
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -68,29 +69,54 @@ def _compile(src, obj, verbose):
     return obj
 
 
+def _digest(paths):
+    h = hashlib.sha256(" ".join(COMMON + HIP_FLAGS).encode())
+    for p in sorted(paths):
+        h.update(os.path.relpath(p, ROOT).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
+    """Build libdcvc_amd.so unless it is already current. "Current" is decided by a content hash
+    of every source/header (file times do not survive the copy to the GPU box)."""
     os.makedirs(OBJ, exist_ok=True)
     srcs = _sources()
-    hdr_time = max([os.path.getmtime(h) for h in _headers()] + [0.0])
+    manifest = LIB + ".manifest"
+    digest = _digest(srcs + _headers())
+    if not force and os.path.exists(LIB) and os.path.exists(manifest):
+        with open(manifest) as f:
+            if f.read().strip() == digest:
+                return LIB
+    hdr_digest = _digest(_headers())
     jobs = []
     objs = []
     for s in srcs:
         rel = os.path.relpath(s, CSRC).replace(os.sep, "__")
         o = os.path.join(OBJ, rel + ".o")
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            jobs.append((s, o))
+        stamp = o + ".stamp"
+        want = hdr_digest + _digest([s])
+        have = open(stamp).read() if os.path.exists(stamp) else ""
+        if force or not os.path.exists(o) or have != want:
+            jobs.append((s, o, stamp, want))
     if jobs:
+        def run(job):
+            _compile(job[0], job[1], verbose)
+            with open(job[2], "w") as f:
+                f.write(job[3])
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-            list(ex.map(lambda a: _compile(a[0], a[1], verbose), jobs))
-    if jobs or not os.path.exists(LIB):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + \
-              ["-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+            list(ex.map(run, jobs))
+    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + \
+          ["-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    with open(manifest, "w") as f:
+        f.write(digest)
     return LIB
 
 

@@ -1,0 +1,177 @@
+// C ABI of the individual kernels (include/dcvc_amd_ops.h).
+#include "capi_common.h"
+#include "dcvc_amd_ops.h"
+#include "kernels/ops.h"
+
+namespace {
+
+using dcvc::half_t;
+
+inline const half_t* H(const void* p) { return static_cast<const half_t*>(p); }
+inline half_t* H(void* p) { return static_cast<half_t*>(p); }
+inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+
+// one lazily allocated page of zeros for padding taps
+const half_t* zero_page()
+{
+    static half_t* z = nullptr;
+    if (!z) {
+        dcvc::hip_check(hipMalloc(&z, 4096), "hipMalloc(zero page)");
+        dcvc::hip_check(hipMemset(z, 0, 4096), "hipMemset(zero page)");
+    }
+    return z;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcvc_conv1x1(const void* x, int ldx, const void* w, const void* bias, const void* r1, int ldr1,
+                 const void* r2, int ldr2, const void* q, const void* q2, void* y, int ldy,
+                 int pixels, int cin, int cout, int flags, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::Conv1x1Desc d;
+        d.x = H(x); d.ldx = ldx; d.w = H(w); d.bias = H(bias);
+        d.r1 = H(r1); d.ldr1 = ldr1; d.r2 = H(r2); d.ldr2 = ldr2;
+        d.q = H(q); d.q2 = H(q2); d.y = H(y); d.ldy = ldy;
+        d.pixels = pixels; d.cin = cin; d.cout = cout;
+        d.wsilu = (flags & DCVC_CONV_WSILU) != 0;
+        d.chunk_add = (flags & DCVC_CONV_CHUNK_ADD) != 0;
+        dcvc::conv1x1(d, S(stream));
+    });
+}
+
+int dcvc_conv_kxk(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy,
+                  int in_h, int in_w, int cin, int cout, int ksize, int stride, int pad, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::ConvKxKDesc d;
+        d.x = H(x); d.ldx = ldx; d.w = H(w); d.bias = H(bias); d.zeros = zero_page();
+        d.y = H(y); d.ldy = ldy; d.in_h = in_h; d.in_w = in_w; d.cin = cin; d.cout = cout;
+        d.ksize = ksize; d.stride = stride; d.pad = pad;
+        dcvc::conv_kxk(d, S(stream));
+    });
+}
+
+int dcvc_tconv2x2(const void* x, int ldx, const void* w, void* y, int ldy, int in_h, int in_w,
+                  int cin, int cout, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::TConv2x2Desc d;
+        d.x = H(x); d.ldx = ldx; d.w = H(w); d.y = H(y); d.ldy = ldy;
+        d.in_h = in_h; d.in_w = in_w; d.cin = cin; d.cout = cout;
+        dcvc::tconv2x2(d, S(stream));
+    });
+}
+
+int dcvc_dwconv3x3(const void* x, int ldx, const void* w, void* y, int ldy, int Hh, int W, int C,
+                   void* stream)
+{
+    return dcvc::guarded([&] { dcvc::dwconv3x3(H(x), ldx, H(w), H(y), ldy, Hh, W, C, S(stream)); });
+}
+
+int dcvc_pad_unshuffle8(const void* x, int Hh, int W, int C3, void* out, int H8, int W8, void* stream)
+{
+    return dcvc::guarded([&] { dcvc::pad_unshuffle8(H(x), Hh, W, C3, H(out), H8, W8, S(stream)); });
+}
+
+int dcvc_shuffle8(const void* in, int ldin, int H8, int W8, int C3, int clamp, void* out, void* stream)
+{
+    return dcvc::guarded([&] { dcvc::shuffle8(H(in), ldin, H8, W8, C3, clamp != 0, H(out), S(stream)); });
+}
+
+int dcvc_shuffle2(const void* in, int ldin, int Hh, int W, int C, void* out, int ldout, void* stream)
+{
+    return dcvc::guarded([&] { dcvc::shuffle2(H(in), ldin, Hh, W, C, H(out), ldout, S(stream)); });
+}
+
+int dcvc_replicate_pad(const void* in, int ldin, int Hh, int W, int C, int pad_b, int pad_r,
+                       void* out, int ldout, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::replicate_pad(H(in), ldin, Hh, W, C, pad_b, pad_r, H(out), ldout, S(stream));
+    });
+}
+
+int dcvc_crop(const void* in, int ldin, int Win, void* out, int ldout, int Hh, int W, int C, void* stream)
+{
+    return dcvc::guarded([&] { dcvc::crop(H(in), ldin, Win, H(out), ldout, Hh, W, C, S(stream)); });
+}
+
+int dcvc_mul_channel(const void* x, int ldx, const void* q, void* y, int ldy, int pixels, int C,
+                     void* stream)
+{
+    return dcvc::guarded([&] { dcvc::mul_channel(H(x), ldx, H(q), H(y), ldy, pixels, C, S(stream)); });
+}
+
+int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::round_z(H(z), H(z_hat), static_cast<int8_t*>(z_i8), count, S(stream));
+    });
+}
+
+int dcvc_int8_to_half(const void* in, void* out, int count, void* stream)
+{
+    return dcvc::guarded([&] { dcvc::int8_to_half(static_cast<const int8_t*>(in), H(out), count, S(stream)); });
+}
+
+int dcvc_symbol_blocks(int count)
+{
+    return dcvc::symbol_blocks(count);
+}
+
+int dcvc_y_step_enc(const void* y, int ldy, const void* scales, int lds, const void* means, int ldm,
+                    void* y_hat_acc, int ldacc, void* sym, void* cond, void* block_count,
+                    void* compact_out, void* totals, int Hh, int W, int C, int step,
+                    float skip_thres, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::symbols_init();
+        dcvc::YStepEnc d;
+        d.y = H(y); d.ldy = ldy; d.scales = H(scales); d.lds = lds; d.means = H(means); d.ldm = ldm;
+        d.y_hat_acc = H(y_hat_acc); d.ldacc = ldacc;
+        d.sym = static_cast<int16_t*>(sym); d.cond = static_cast<uint8_t*>(cond);
+        d.block_count = static_cast<int32_t*>(block_count);
+        d.H = Hh; d.W = W; d.C = C; d.step = step; d.skip_thres = skip_thres; d.first = (step == 0);
+        dcvc::y_step_enc(d, S(stream));
+        dcvc::compact(sym, 2, d.cond, d.block_count, Hh * W * (C / 4), compact_out,
+                      static_cast<int32_t*>(totals), step, S(stream));
+    });
+}
+
+int dcvc_y_step_dec_index(const void* scales, int lds, void* index, void* cond, void* block_count,
+                          void* compact_out, void* totals, int Hh, int W, int C, int step,
+                          float skip_thres, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::symbols_init();
+        dcvc::YStepDecIndex d;
+        d.scales = H(scales); d.lds = lds;
+        d.index = static_cast<uint8_t*>(index); d.cond = static_cast<uint8_t*>(cond);
+        d.block_count = static_cast<int32_t*>(block_count);
+        d.H = Hh; d.W = W; d.C = C; d.step = step; d.skip_thres = skip_thres;
+        dcvc::y_step_dec_index(d, S(stream));
+        dcvc::compact(index, 1, d.cond, d.block_count, Hh * W * (C / 4), compact_out,
+                      static_cast<int32_t*>(totals), step, S(stream));
+    });
+}
+
+int dcvc_y_step_dec_restore(const void* decoded, const void* cond, const void* block_count,
+                            const void* totals, const void* means, int ldm, void* y_hat_acc,
+                            int ldacc, int Hh, int W, int C, int step, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::YStepDecRestore d;
+        d.decoded = static_cast<const int8_t*>(decoded);
+        d.cond = static_cast<const uint8_t*>(cond);
+        d.block_count = static_cast<const int32_t*>(block_count);
+        d.totals = static_cast<const int32_t*>(totals); d.slot = step;
+        d.means = H(means); d.ldm = ldm; d.y_hat_acc = H(y_hat_acc); d.ldacc = ldacc;
+        d.H = Hh; d.W = W; d.C = C; d.step = step; d.first = (step == 0);
+        dcvc::y_step_dec_restore(d, S(stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,408 @@
+// conv_gemm.hip - the contraction kernel of the codec: every dense convolution of DCVC-UF
+// (1x1, 2x2 stride 2, 3x3 stride 1/2, and the 2x2 stride-2 transposed conv) as one NHWC
+// implicit GEMM on the gfx950 matrix cores with the fused epilogues of the reference's ten
+// CUTLASS entry points:
+//
+//   conv1x1_bias                    conv1x1_bias.cu:524-540
+//   conv1x1_bias_wsilu              conv1x1_bias_wsilu.cu:230-248
+//   conv1x1_bias_shortcut           conv1x1_bias_shortcut.cu:230-247
+//   conv1x1_bias_shortcut2          conv1x1_bias_shortcut2.cu:81-100
+//   conv1x1_bias_shortcut_with_quant / conv1x1_bias_with_quant   (…_with_quant.cu)
+//   conv1x1_bias_wsilu_chunk_add    conv1x1_bias_wsilu_chunk_add.cu:356-390
+//   conv_bias (k in {2,3}, stride in {1,2})   conv_bias.cu:131-151
+//   transposed_conv (2x2, stride 2)           transposed_conv.cu:101-119
+//
+// Design (MI355X-first, not a CUTLASS translation):
+//   * D^T = W * X^T: the weight fragment is the MFMA "A" operand and the activation fragment
+//     the "B" operand of v_mfma_f32_32x32x16_f16, so a lane's 16 accumulators are 4 groups of 4
+//     CONSECUTIVE output channels of ONE pixel. chunk-add (sum of 4 adjacent channels) is then a
+//     purely in-register reduction and the NHWC store is channel-contiguous.
+//   * 128(pixels) x 128(channels) x 64(k) block tile, 4 waves (2x2), each wave 64x64 =
+//     2x2 MFMA tiles; fp32 accumulation, k ascending in steps of 16 (fixed order -> results do
+//     not depend on the tile shape; the oracle restates the same order).
+//   * global -> LDS staging by global_load_lds (16 B per lane, no VGPR round trip), two LDS
+//     stages, one barrier per k-step. The LDS image is lane-linear, so the bank-conflict swizzle
+//     (16-B chunk index XOR ((row >> 1) & 7)) is applied to the per-lane SOURCE address and to
+//     the ds_read_b128 fragment address.
+//   * every operand is (pointer, leading dimension): channel-slice views of wider NHWC buffers
+//     are first-class (the reference's free torch.cat, conv1x1_kernel.h:82,102-107).
+//   * epilogue straight from the accumulators: v_permlane32_swap pairs the two half-waves so
+//     each lane owns 8 consecutive channels -> 16-B bias / residual loads and 16-B stores.
+//   * XCD-aware block order: consecutive logical tiles (same pixel rows, adjacent channel tiles)
+//     run on the same XCD and share the activation tile in that XCD's L2.
+#include "arith.h"
+#include "ops.h"
+
+#include <stdexcept>
+#include <string>
+
+namespace dcvc {
+
+namespace {
+
+constexpr int BM = 128;            // pixels per block tile
+constexpr int BN = 128;            // output channels (pre chunk-add) per block tile
+constexpr int BK = 64;             // k per stage
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB, same for the activation and the weight tile
+constexpr int NTHREADS = 256;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct ConvGemmParams {
+    const half_t* x;      // activations, pixel stride ldx
+    const half_t* w;      // [N][K] (k contiguous; for k x k convs K = taps * Cin, tap major)
+    const half_t* bias;   // [N] or nullptr
+    const half_t* r1;     // residual 1 (pixel stride ldr1) or nullptr
+    const half_t* r2;     // residual 2 or nullptr
+    const half_t* q;      // per-channel scale [Nout] (fused "with_quant") or nullptr
+    const half_t* q2;     // second per-channel scale applied to the ROUNDED output (models the
+                          // reference's separate multiply_with_broadcast kernel) or nullptr
+    const half_t* zeros;  // >= 128 B of zeros (padding taps)
+    half_t* y;            // output, pixel stride ldy
+    int ldx, ldr1, ldr2, ldy;
+    int M, N, K;          // output pixels, output channels (pre chunk-add), contraction length
+    // spatial description (k x k convs and the transposed conv)
+    int in_h, in_w, out_h, out_w;   // input / output grid
+    int cin, ksize, stride, pad;
+    int up_dy, up_dx;               // transposed conv: this launch writes pixel (2y+dy, 2x+dx)
+};
+
+enum : int { ACT_NONE = 0, ACT_WSILU = 1 };
+
+// ---------------------------------------------------------------------------------------------
+template <bool SPATIAL>
+__device__ __forceinline__ const half_t* x_row_ptr(const ConvGemmParams& p, int m, int k0)
+{
+    if constexpr (!SPATIAL) {
+        return p.x + static_cast<size_t>(m) * p.ldx + k0;
+    } else {
+        const int tap = k0 / p.cin;
+        const int c0 = k0 - tap * p.cin;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const int oy = m / p.out_w, ox = m - oy * p.out_w;
+        const int iy = oy * p.stride + ky - p.pad;
+        const int ix = ox * p.stride + kx - p.pad;
+        if (iy < 0 || iy >= p.in_h || ix < 0 || ix >= p.in_w) {
+            return p.zeros;
+        }
+        return p.x + (static_cast<size_t>(iy) * p.in_w + ix) * p.ldx + c0;
+    }
+}
+
+template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+__global__ void __launch_bounds__(NTHREADS, 2)
+conv_gemm_kernel(const ConvGemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (X tile, W tile)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5;
+
+    // ---- XCD-aware tile order (bijective chunking: XCD x gets a contiguous range of tiles)
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int tile;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int qn = nwg >> 3, rn = nwg & 7;
+        tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+    }
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+
+    // ---- staging plan: thread t moves 16-B unit u = j*256 + t of each tile, j = 0..3
+    //      unit u -> row u>>3, physical chunk u&7; logical chunk = physical ^ ((row>>1)&7)
+    const int srow = tid >> 3;                       // 0..31 (+32 j)
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    int xrow[4];
+    const half_t* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = j * 32 + srow;
+        xrow[j] = min(m0 + r, p.M - 1);
+        wsrc[j] = p.w + static_cast<size_t>(min(n0 + r, p.N - 1)) * p.K + schunk * 8;
+    }
+
+    auto stage = [&](int buf, int k0) {
+        char* xs = smem + buf * (2 * TILE_BYTES);
+        char* ws = xs + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int unit0 = j * 256 + wave * 64;            // wave-uniform LDS destination
+            const half_t* xsrc = x_row_ptr<SPATIAL>(p, xrow[j], k0) + schunk * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)xsrc, (lptr_t)(xs + unit0 * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(ws + unit0 * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a tile) for the four 16-wide k slices
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        foff[s] = frow * 128 + (((s * 2 + hi) ^ fsw) << 4);
+    }
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const bool wave_active = (n0 + wn * 64) < p.N;   // N is a multiple of 64
+    const int nk = p.K / BK;
+
+    stage(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();                 // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
+        if (t + 1 < nk) {
+            stage((t + 1) & 1, (t + 1) * BK);
+        }
+        const char* xs = smem + (t & 1) * (2 * TILE_BYTES) + wm * (64 * 128);
+        const char* ws = smem + (t & 1) * (2 * TILE_BYTES) + TILE_BYTES + wn * (64 * 128);
+        if (wave_active) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                half8 xf[2], wf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    xf[i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s]);
+                    wf[i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_active) {
+        return;
+    }
+
+    // ---- epilogue. acc[nt][mt][r]: pixel m = m0 + wm*64 + mt*32 + (lane&31),
+    //      channel n = n0 + wn*64 + nt*32 + 8*(r>>2) + 4*hi + (r&3)
+    const int nbase = n0 + wn * 64;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wm * 64 + mt * 32 + (lane & 31);
+        const bool m_ok = m < p.M;
+        size_t orow;                                  // output pixel index
+        if constexpr (UPSAMPLE) {
+            const int yy = m / p.in_w, xx = m - yy * p.in_w;
+            orow = static_cast<size_t>(2 * yy + p.up_dy) * (2 * p.in_w) + (2 * xx + p.up_dx);
+        } else {
+            orow = static_cast<size_t>(m);
+        }
+        if constexpr (CHUNK) {
+            // z = wsilu(acc + bias) ; s = ((z0 + z1) + z2) + z3 over 4 adjacent channels
+            float s[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nbase + nt * 32 + 8 * g + 4 * hi;
+                    const half4 b4 = *reinterpret_cast<const half4*>(p.bias + n);
+                    float z[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[nt][mt][4 * g + e] + static_cast<float>(b4[e]);
+                        z[e] = (ACT == ACT_WSILU) ? wsilu_spec(v) : v;
+                    }
+                    s[nt][g] = ((z[0] + z[1]) + z[2]) + z[3];
+                }
+            // lower half-wave collects the 8 outputs of nt = 0, upper half-wave those of nt = 1
+            half8 o;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[0][g]),
+                                                                 __float_as_uint(s[1][g]), false, false);
+                o[2 * g] = to_half(__uint_as_float(sw[0]));
+                o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
+            }
+            if (m_ok) {
+                const int co = (nbase >> 2) + hi * 8;
+                *reinterpret_cast<half8*>(p.y + orow * p.ldy + co) = o;
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {          // pair of 4-channel groups (2pr, 2pr+1)
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(
+                            __float_as_uint(acc[nt][mt][8 * pr + e]),
+                            __float_as_uint(acc[nt][mt][8 * pr + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw[0]);
+                        v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    // this lane now holds channels cb .. cb+7 of pixel m
+                    const int cb = nbase + nt * 32 + 16 * pr + 8 * hi;
+                    if (p.bias != nullptr) {
+                        const half8 b8 = *reinterpret_cast<const half8*>(p.bias + cb);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(b8[e]);
+                    }
+                    if constexpr (ACT == ACT_WSILU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = wsilu_spec(v[e]);
+                    }
+                    if (m_ok) {
+                        if constexpr (NRES >= 1) {
+                            const half8 r8 = *reinterpret_cast<const half8*>(
+                                p.r1 + static_cast<size_t>(m) * p.ldr1 + cb);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
+                        }
+                        if constexpr (NRES >= 2) {
+                            const half8 r8 = *reinterpret_cast<const half8*>(
+                                p.r2 + static_cast<size_t>(m) * p.ldr2 + cb);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
+                        }
+                        if constexpr (QUANT) {
+                            const half8 q8 = *reinterpret_cast<const half8*>(p.q + cb);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
+                        }
+                        half8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                        if (p.q2 != nullptr) {
+                            const half8 q8 = *reinterpret_cast<const half8*>(p.q2 + cb);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
+                        }
+                        *reinterpret_cast<half8*>(p.y + orow * p.ldy + cb) = o;
+                    }
+                }
+        }
+    }
+}
+
+template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+void launch(const ConvGemmParams& p, hipStream_t stream)
+{
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    auto kern = conv_gemm_kernel<SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>;
+    static bool attr_set = false;
+    const int smem_bytes = 4 * TILE_BYTES;
+    if (!attr_set) {
+        hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
+                  "hipFuncSetAttribute(conv_gemm)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), smem_bytes, stream, p);
+    hip_check(hipGetLastError(), "conv_gemm launch");
+}
+
+void check_common(const ConvGemmParams& p)
+{
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) {
+        throw std::invalid_argument("conv_gemm: empty problem");
+    }
+    if (p.K % BK != 0 || p.N % 64 != 0) {
+        throw std::invalid_argument("conv_gemm: K must be a multiple of 64 and N of 64 (K=" +
+                                    std::to_string(p.K) + ", N=" + std::to_string(p.N) + ")");
+    }
+    if ((p.ldx % 8) || (p.ldy % 8) || (p.r1 && p.ldr1 % 8) || (p.r2 && p.ldr2 % 8)) {
+        throw std::invalid_argument("conv_gemm: leading dimensions must be multiples of 8 channels");
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// public launchers (ops.h)
+// ------------------------------------------------------------------------------------------
+void conv1x1(const Conv1x1Desc& d, hipStream_t stream)
+{
+    ConvGemmParams p{};
+    p.x = d.x;  p.ldx = d.ldx;
+    p.w = d.w;  p.bias = d.bias;
+    p.r1 = d.r1; p.ldr1 = d.ldr1;
+    p.r2 = d.r2; p.ldr2 = d.ldr2;
+    p.q = d.q;  p.q2 = d.q2;
+    p.zeros = nullptr;
+    p.y = d.y;  p.ldy = d.ldy;
+    p.M = d.pixels; p.N = d.cout; p.K = d.cin;
+    check_common(p);
+    const int nres = (d.r1 ? 1 : 0) + (d.r2 ? 1 : 0);
+    if (d.r2 && !d.r1) {
+        throw std::invalid_argument("conv1x1: r2 without r1");
+    }
+    if (d.chunk_add) {
+        if (!d.bias || nres || d.q || d.q2 || d.cout % 256 != 0) {
+            throw std::invalid_argument("conv1x1: chunk-add needs bias, no residual/quant, N % 256 == 0");
+        }
+        if (d.wsilu) launch<false, ACT_WSILU, true, 0, false, false>(p, stream);
+        else         launch<false, ACT_NONE, true, 0, false, false>(p, stream);
+        return;
+    }
+    if (d.wsilu) {
+        if (nres || d.q) throw std::invalid_argument("conv1x1: wsilu with residual/quant is not a reference op");
+        launch<false, ACT_WSILU, false, 0, false, false>(p, stream);
+        return;
+    }
+    if (d.q) {
+        if (nres == 0)      launch<false, ACT_NONE, false, 0, true, false>(p, stream);
+        else if (nres == 1) launch<false, ACT_NONE, false, 1, true, false>(p, stream);
+        else throw std::invalid_argument("conv1x1: quant with two residuals is not a reference op");
+        return;
+    }
+    if (nres == 0)      launch<false, ACT_NONE, false, 0, false, false>(p, stream);
+    else if (nres == 1) launch<false, ACT_NONE, false, 1, false, false>(p, stream);
+    else                launch<false, ACT_NONE, false, 2, false, false>(p, stream);
+}
+
+void conv_kxk(const ConvKxKDesc& d, hipStream_t stream)
+{
+    ConvGemmParams p{};
+    p.x = d.x;  p.ldx = d.ldx;
+    p.w = d.w;  p.bias = d.bias;
+    p.zeros = d.zeros;
+    p.y = d.y;  p.ldy = d.ldy;
+    p.in_h = d.in_h; p.in_w = d.in_w;
+    p.out_h = (d.in_h + 2 * d.pad - d.ksize) / d.stride + 1;
+    p.out_w = (d.in_w + 2 * d.pad - d.ksize) / d.stride + 1;
+    p.cin = d.cin; p.ksize = d.ksize; p.stride = d.stride; p.pad = d.pad;
+    p.M = p.out_h * p.out_w; p.N = d.cout; p.K = d.ksize * d.ksize * d.cin;
+    check_common(p);
+    if (d.cin % BK != 0 || !d.zeros) {
+        throw std::invalid_argument("conv_kxk: Cin must be a multiple of 64 and a zero page is required");
+    }
+    launch<true, ACT_NONE, false, 0, false, false>(p, stream);
+}
+
+void tconv2x2(const TConv2x2Desc& d, hipStream_t stream)
+{
+    // out[2y+dy][2x+dx][co] = sum_ci x[y][x][ci] * w[(dy*2+dx)][co][ci]   (no bias: the reference
+    // folds SubpelConv2x(kernel 1) into a stride-2 transposed conv, layers_proxy.cpp:320-323)
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            ConvGemmParams p{};
+            p.x = d.x;  p.ldx = d.ldx;
+            p.w = d.w + static_cast<size_t>(dy * 2 + dx) * d.cout * d.cin;
+            p.bias = nullptr;
+            p.y = d.y;  p.ldy = d.ldy;
+            p.in_h = d.in_h; p.in_w = d.in_w;
+            p.up_dy = dy; p.up_dx = dx;
+            p.M = d.in_h * d.in_w; p.N = d.cout; p.K = d.cin;
+            check_common(p);
+            launch<false, ACT_NONE, false, 0, false, true>(p, stream);
+        }
+}
+
+}  // namespace dcvc

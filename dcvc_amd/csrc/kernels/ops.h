@@ -1,0 +1,139 @@
+// Host-side launch interface of the HIP kernels (raw device pointers + explicit leading
+// dimensions, everything on the caller's stream; nothing here allocates or synchronises, so all
+// of it can be captured into a hipGraph).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace dcvc {
+
+typedef _Float16 half_t;
+
+inline void hip_check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) {
+        throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    }
+}
+
+// ---------------------------------------------------------------- dense convolutions (conv_gemm.hip)
+struct Conv1x1Desc {
+    const half_t* x = nullptr; int ldx = 0;     // [pixels][ldx], first `cin` channels of each pixel
+    const half_t* w = nullptr;                  // [cout][cin]
+    const half_t* bias = nullptr;               // [cout] or null
+    const half_t* r1 = nullptr; int ldr1 = 0;   // residuals (added in fp32 before the rounding)
+    const half_t* r2 = nullptr; int ldr2 = 0;
+    const half_t* q = nullptr;                  // fused per-channel scale (…_with_quant)
+    const half_t* q2 = nullptr;                 // per-channel scale applied to the rounded fp16 output
+    half_t* y = nullptr; int ldy = 0;           // [pixels][ldy]; cout (or cout/4 with chunk_add) channels
+    int pixels = 0, cin = 0, cout = 0;
+    bool wsilu = false, chunk_add = false;
+};
+void conv1x1(const Conv1x1Desc& d, hipStream_t stream);
+
+struct ConvKxKDesc {
+    const half_t* x = nullptr; int ldx = 0;     // [in_h][in_w][ldx]
+    const half_t* w = nullptr;                  // [cout][ky][kx][cin]  (tap major, cin contiguous)
+    const half_t* bias = nullptr;
+    const half_t* zeros = nullptr;              // >= 128 B of zeros
+    half_t* y = nullptr; int ldy = 0;           // [out_h][out_w][ldy]
+    int in_h = 0, in_w = 0, cin = 0, cout = 0, ksize = 0, stride = 1, pad = 0;
+};
+void conv_kxk(const ConvKxKDesc& d, hipStream_t stream);
+
+struct TConv2x2Desc {
+    const half_t* x = nullptr; int ldx = 0;     // [in_h][in_w][ldx]
+    const half_t* w = nullptr;                  // [4 = dy*2+dx][cout][cin]
+    half_t* y = nullptr; int ldy = 0;           // [2 in_h][2 in_w][ldy]
+    int in_h = 0, in_w = 0, cin = 0, cout = 0;
+};
+void tconv2x2(const TConv2x2Desc& d, hipStream_t stream);
+
+// ---------------------------------------------------------------- depthwise 3x3 (dwconv.hip)
+// y[h][w][c] = sum_{ky,kx} x[h+ky-1][w+kx-1][c] * wt[ky][kx][c]   (zero padding, no bias: the
+// reference folds the bias into the next 1x1, layers_proxy.cpp:175-178)
+void dwconv3x3(const half_t* x, int ldx, const half_t* wt /* [9][C] */, half_t* y, int ldy,
+               int H, int W, int C, hipStream_t stream);
+
+// ---------------------------------------------------------------- layout kernels (layout.hip)
+// x: [H][W][C3] (channels_last view of [1, C3, H, W]); out: [H8][W8][C3*64], replicate padding.
+void pad_unshuffle8(const half_t* x, int H, int W, int C3, half_t* out, int H8, int W8,
+                    hipStream_t stream);
+// in: [H8][W8][C3*64] -> out: [H8*8][W8*8][C3] with optional clamp to [-0.5, 0.5]
+void shuffle8(const half_t* in, int ldin, int H8, int W8, int C3, bool clamp, half_t* out,
+              hipStream_t stream);
+// in: [H][W][4*C] -> out [2H][2W][C]   (pixel_shuffle(2), HT-L biased SubpelConv2x)
+void shuffle2(const half_t* in, int ldin, int H, int W, int C, half_t* out, int ldout,
+              hipStream_t stream);
+// replicate pad bottom/right: in [H][W][C] -> out [H+pb][W+pr][C]; with pb = pr = 0 a strided copy
+void replicate_pad(const half_t* in, int ldin, int H, int W, int C, int pad_b, int pad_r,
+                   half_t* out, int ldout, hipStream_t stream);
+// crop: in [Hin][Win][C] -> out [H][W][C]
+void crop(const half_t* in, int ldin, int Win, half_t* out, int ldout, int H, int W, int C,
+          hipStream_t stream);
+// y = x * q[c] (fp16 multiply, may be in place)
+void mul_channel(const half_t* x, int ldx, const half_t* q, half_t* y, int ldy, int pixels, int C,
+                 hipStream_t stream);
+
+// ---------------------------------------------------------------- symbol kernels (symbols.hip)
+// Uploads the scale -> Gaussian-table-index lookup table (call once per process before the
+// first symbol kernel and outside any graph capture).
+void symbols_init();
+// number of 2048-element blocks the symbol kernels use for `count` elements (= size of block_count)
+int symbol_blocks(int count);
+
+// z -> round half away, clamp [-64, 63] -> fp16 z_hat and int8 symbols
+void round_z(const half_t* z, half_t* z_hat, int8_t* z_i8, int count, hipStream_t stream);
+void int8_to_half(const int8_t* in, half_t* out, int count, hipStream_t stream);
+
+// One step (0..3) of the 4-step masked quantisation of y (encoder side): fuses the reference's
+// process_with_mask + single_part_for_writing_4x (x2) + build_index_enc + compaction counting.
+struct YStepEnc {
+    const half_t* y = nullptr; int ldy = 0;            // scaled latent [P][C]
+    const half_t* scales = nullptr; int lds = 0;       // [P][C]
+    const half_t* means = nullptr; int ldm = 0;        // [P][C]
+    half_t* y_hat_acc = nullptr; int ldacc = 0;        // y_hat_so_far [P][C] (written for the active group)
+    int16_t* sym = nullptr;                            // [P * C/4] (symbol << 8) + index, NHWC order
+    uint8_t* cond = nullptr;                           // [P * C/4 / 8] 8 skip flags per byte
+    int32_t* block_count = nullptr;                    // [blocks] kept symbols per 2048-element block
+    int H = 0, W = 0, C = 0, step = 0;
+    float skip_thres = 0.f;
+    bool first = false;                                // step 0 initialises y_hat_acc (copy, not add)
+};
+void y_step_enc(const YStepEnc& d, hipStream_t stream);
+
+// Decoder side: scales of the active group -> table index + skip flag (+ counting)
+struct YStepDecIndex {
+    const half_t* scales = nullptr; int lds = 0;
+    uint8_t* index = nullptr;                          // [P * C/4]
+    uint8_t* cond = nullptr;
+    int32_t* block_count = nullptr;
+    int H = 0, W = 0, C = 0, step = 0;
+    float skip_thres = 0.f;
+};
+void y_step_dec_index(const YStepDecIndex& d, hipStream_t stream);
+
+// Stream compaction out[base + rank] = in[i] for kept i (ELEM = 2: int16 symbols, 1: uint8 index).
+// base = total[0..slot) summed; total[slot] receives this step's kept count.
+void compact(const void* in, int elem_bytes, const uint8_t* cond, const int32_t* block_count,
+             int count, void* out, int32_t* totals, int slot, hipStream_t stream);
+
+// Decoder: scatter decoded int8 symbols back (zeros where skipped), add the mean of the active
+// group and accumulate into y_hat_so_far (restore_y_4x*, stream.cu:757-844).
+struct YStepDecRestore {
+    const int8_t* decoded = nullptr;                   // compacted, this step's symbols start at totals-base
+    const uint8_t* cond = nullptr;
+    const int32_t* block_count = nullptr;
+    const int32_t* totals = nullptr; int slot = 0;
+    const half_t* means = nullptr; int ldm = 0;
+    half_t* y_hat_acc = nullptr; int ldacc = 0;
+    int H = 0, W = 0, C = 0, step = 0;
+    bool first = false;
+};
+void y_step_dec_restore(const YStepDecRestore& d, hipStream_t stream);
+
+}  // namespace dcvc

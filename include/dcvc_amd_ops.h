@@ -1,0 +1,85 @@
+/*
+ * dcvc_amd_ops.h - C ABI of the individual HIP kernels (libdcvc_amd.so).
+ *
+ * One entry point per device function the reference's proxies call
+ *   /root/reference/src/layers/extensions/inference/def_cutlass.h:10-40     (fused conv ops)
+ *   /root/reference/src/layers/extensions/inference/def_elementwise.h:10-78 (elementwise ops)
+ * with at::Tensor replaced by (device pointer, leading dimension, sizes). All tensors are fp16
+ * NHWC ("channels_last") on the current HIP device; `stream` is a hipStream_t (0 = default).
+ * Nothing allocates or synchronises. Returns 0, or -1 with dcvc_last_error() set.
+ */
+#ifndef DCVC_AMD_OPS_H
+#define DCVC_AMD_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flags for dcvc_conv1x1 */
+#define DCVC_CONV_WSILU      1   /* y = wsilu(acc + bias)                     (conv1x1_bias_wsilu)            */
+#define DCVC_CONV_CHUNK_ADD  2   /* sum of 4 adjacent output channels         (conv1x1_bias_wsilu_chunk_add)  */
+
+/* def_cutlass.h:10-33: conv1x1_bias / _wsilu / _shortcut / _shortcut2 / _shortcut_with_quant /
+ * _with_quant / _wsilu_chunk_add, selected by which optional pointers are non-NULL and `flags`.
+ *   y[p][n] = fp16( ((acc + bias[n]) (wsilu) + r1[p][n] + r2[p][n]) * q[n] ), then * q2[n] in fp16.
+ * x: [pixels][ldx] (first cin channels), w: [cout][cin], y: [pixels][ldy]. */
+int dcvc_conv1x1(const void* x, int ldx, const void* w, const void* bias,
+                 const void* r1, int ldr1, const void* r2, int ldr2,
+                 const void* q, const void* q2, void* y, int ldy,
+                 int pixels, int cin, int cout, int flags, void* stream);
+
+/* def_cutlass.h:35-37 conv_bias: dense k x k conv (k in {2,3}), stride in {1,2}, zero padding.
+ * w: [cout][k][k][cin] (tap-major re-layout of the PyTorch [cout][cin][k][k] weight). */
+int dcvc_conv_kxk(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy,
+                  int in_h, int in_w, int cin, int cout, int ksize, int stride, int pad,
+                  void* stream);
+
+/* def_cutlass.h:39-40 transposed_conv: 2x2, stride 2, no bias. w: [4 = dy*2+dx][cout][cin]. */
+int dcvc_tconv2x2(const void* x, int ldx, const void* w, void* y, int ldy,
+                  int in_h, int in_w, int cin, int cout, void* stream);
+
+/* def_cutlass.h:34 d3x3: depthwise 3x3, pad 1, no bias. w: [9][C]. */
+int dcvc_dwconv3x3(const void* x, int ldx, const void* w, void* y, int ldy, int H, int W, int C,
+                   void* stream);
+
+/* def_elementwise.h: pad_and_unshuffle_8_cuda / pixel_shuffle_8_cuda / pixel_shuffle_2_cuda /
+ * replicate_pad_cuda / slice_cuda / multiply_with_broadcast_cuda */
+int dcvc_pad_unshuffle8(const void* x, int H, int W, int C3, void* out, int H8, int W8, void* stream);
+int dcvc_shuffle8(const void* in, int ldin, int H8, int W8, int C3, int clamp, void* out, void* stream);
+int dcvc_shuffle2(const void* in, int ldin, int H, int W, int C, void* out, int ldout, void* stream);
+int dcvc_replicate_pad(const void* in, int ldin, int H, int W, int C, int pad_b, int pad_r,
+                       void* out, int ldout, void* stream);
+int dcvc_crop(const void* in, int ldin, int Win, void* out, int ldout, int H, int W, int C, void* stream);
+int dcvc_mul_channel(const void* x, int ldx, const void* q, void* y, int ldy, int pixels, int C,
+                     void* stream);
+
+/* def_elementwise.h: round_z_cuda / int8_to_dtype_cuda */
+int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream);
+int dcvc_int8_to_half(const void* in, void* out, int count, void* stream);
+
+/* One autoregressive step of the 4x masked y coding, encoder side. Fuses
+ * process_with_mask_cuda + single_part_for_writing_4x_cuda (x2) + build_index_enc_cuda +
+ * conditional_index_part1_cuda (def_elementwise.h). Outputs: y_hat_acc (active group written;
+ * step 0 also zeroes the other groups), sym[P*C/4] int16, cond bits, per-block counts, then the
+ * compacted symbols out[...] and totals[step]. n_blocks = dcvc_symbol_blocks(P*C/4). */
+int dcvc_symbol_blocks(int count);
+int dcvc_y_step_enc(const void* y, int ldy, const void* scales, int lds, const void* means, int ldm,
+                    void* y_hat_acc, int ldacc, void* sym, void* cond, void* block_count,
+                    void* compact_out, void* totals,
+                    int H, int W, int C, int step, float skip_thres, void* stream);
+/* decoder side, part 1: single_part_for_reading_4x_cuda + build_index_dec_cuda + compaction */
+int dcvc_y_step_dec_index(const void* scales, int lds, void* index, void* cond, void* block_count,
+                          void* compact_out, void* totals,
+                          int H, int W, int C, int step, float skip_thres, void* stream);
+/* decoder side, part 2: conditional_recover_with_type_conversion_cuda + restore_y_4x*_cuda.
+ * decoded: int8 symbols of ALL steps so far, this step's start at sum(totals[0..step)). */
+int dcvc_y_step_dec_restore(const void* decoded, const void* cond, const void* block_count,
+                            const void* totals, const void* means, int ldm,
+                            void* y_hat_acc, int ldacc, int H, int W, int C, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCVC_AMD_OPS_H */

@@ -9,6 +9,7 @@
 
 Usage: python oracle/build_oracle.py [--force]
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -19,11 +20,26 @@ REF_RANS = "/root/reference/src/cpp/py_rans"
 C_SOURCES = ["rans_oracle.c", "nn_oracle.c"]
 
 
+def _digest(sources):
+    h = hashlib.sha256()
+    for s in sorted(sources):
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale(target, sources):
-    if not os.path.exists(target):
+    """Content-hash staleness (file times do not survive the copy to the GPU box)."""
+    stamp = target + ".manifest"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    with open(stamp) as f:
+        return f.read().strip() != _digest(sources)
+
+
+def _mark(target, sources):
+    with open(target + ".manifest", "w") as f:
+        f.write(_digest(sources))
 
 
 def build_liboracle(force=False):
@@ -35,6 +51,7 @@ def build_liboracle(force=False):
         cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                "-fno-fast-math", "-Wall", "-Wextra", "-o", out] + srcs + ["-lm"]
         subprocess.check_call(cmd)
+        _mark(out, srcs)
     return out
 
 
@@ -52,6 +69,7 @@ def build_ref(force=False):
                "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
                "-o", out] + srcs + ["-lpthread"]
         subprocess.check_call(cmd)
+        _mark(out, srcs)
     return out
 
 

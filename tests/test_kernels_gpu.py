@@ -1,0 +1,263 @@
+"""Per-kernel parity on a real MI355X (-m gpu), through the C ABI.
+
+Dense convolutions are checked against a plain PyTorch fp32 reference of the same op (fp16
+inputs, fp32 math, one rounding) within a 1-2 fp16-ulp tolerance; integer / layout / symbol
+kernels are checked bit-exactly against the numpy oracle (oracle/symbols_np.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    from gpu_util import Ops
+    return Ops()
+
+
+def _rand(shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def _wsilu(x):
+    return x * torch.sigmoid(4.0 * x)
+
+
+def _close(got, want, what, rtol=2e-3, atol=2e-3):
+    got = got.float().cpu()
+    want = want.float().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = (err > tol).sum().item()
+    print("%s: max abs err %.3e, max |want| %.3e, violations %d / %d" %
+          (what, err.max().item(), want.abs().max().item(), bad, err.numel()))
+    assert bad == 0, what
+
+
+CONV_CASES = [
+    # pixels, cin, cout, ldx_extra, flags/residual config
+    dict(P=1000, K=192, N=384, name="bias"),
+    dict(P=384, K=384, N=384, wsilu=True, name="bias_wsilu"),
+    dict(P=777, K=256, N=512, r1=True, name="bias_shortcut"),
+    dict(P=640, K=128, N=128, r1=True, r2=True, name="bias_shortcut2"),
+    dict(P=500, K=128, N=256, r1=True, q=True, name="bias_shortcut_with_quant"),
+    dict(P=300, K=256, N=256, q=True, name="bias_with_quant"),
+    dict(P=900, K=128, N=512, wsilu=True, chunk=True, name="bias_wsilu_chunk_add"),
+    dict(P=2048, K=384, N=1536, wsilu=True, chunk=True, name="bias_wsilu_chunk_add_384"),
+    dict(P=129, K=512, N=192, q2=True, name="bias_then_scale_n192"),
+    dict(P=4096, K=2048, N=512, name="bias_k2048"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c["name"] for c in CONV_CASES])
+def test_conv1x1(ops, case):
+    from gpu_util import call, ptr, stream
+    from dcvc_amd.plugin import MLCodec_extensions_cpp  # noqa: F401  (loads the library)
+    P, K, N = case["P"], case["K"], case["N"]
+    dev = "cuda"
+    ldx = K + 64                      # activations are a channel slice of a wider buffer
+    xw = _rand((P, ldx), 1.0, 1).to(dev)
+    x = xw[:, 32:32 + K]
+    w = _rand((N, K), 1.0 / K ** 0.5, 2).to(dev)
+    b = _rand((N,), 0.5, 3).to(dev)
+    nout = N // 4 if case.get("chunk") else N
+    r1 = _rand((P, nout), 1.0, 4).to(dev) if case.get("r1") else None
+    r2 = _rand((P, nout), 1.0, 5).to(dev) if case.get("r2") else None
+    q = (_rand((nout,), 0.3, 6) + 1).to(dev) if case.get("q") else None
+    q2 = (_rand((nout,), 0.3, 7) + 1).to(dev) if case.get("q2") else None
+    ldy = nout + 8
+    yw = torch.zeros((P, ldy), dtype=torch.half, device=dev)
+    flags = (1 if case.get("wsilu") else 0) | (2 if case.get("chunk") else 0)
+    call(ops.conv1x1, ptr(x), ldx, ptr(w), ptr(b), ptr(r1), nout, ptr(r2), nout, ptr(q), ptr(q2),
+         ptr(yw), ldy, P, K, N, flags, stream())
+    torch.cuda.synchronize()
+    acc = x.float() @ w.float().t() + b.float()
+    if case.get("wsilu"):
+        acc = _wsilu(acc)
+    if case.get("chunk"):
+        acc = acc.view(P, N // 4, 4).sum(-1)
+    if r1 is not None:
+        acc = acc + r1.float()
+    if r2 is not None:
+        acc = acc + r2.float()
+    if q is not None:
+        acc = acc * q.float()
+    want = acc.half()
+    if q2 is not None:
+        want = (want.float() * q2.float()).half()
+    _close(yw[:, :nout], want, "conv1x1 " + case["name"])
+    assert torch.count_nonzero(yw[:, nout:]).item() == 0, "wrote outside the channel slice"
+
+
+@pytest.mark.parametrize("k,s,p,H,W,cin,cout", [(3, 2, 1, 18, 30, 128, 128), (2, 2, 0, 34, 60, 64, 128),
+                                                (3, 1, 1, 17, 15, 64, 256), (3, 2, 1, 17, 31, 192, 256)])
+def test_conv_kxk(ops, k, s, p, H, W, cin, cout):
+    from gpu_util import call, ptr, stream, nhwc
+    dev = "cuda"
+    x = _rand((1, cin, H, W), 1.0, 11).to(dev)
+    w = _rand((cout, cin, k, k), 1.0 / (cin * k * k) ** 0.5, 12).to(dev)
+    b = _rand((cout,), 0.5, 13).to(dev)
+    want = F.conv2d(x.float(), w.float(), b.float(), stride=s, padding=p).half()
+    Ho, Wo = want.shape[2], want.shape[3]
+    xh = nhwc(x)
+    wt = w.permute(0, 2, 3, 1).contiguous()          # [cout][ky][kx][cin]
+    y = torch.zeros((Ho, Wo, cout), dtype=torch.half, device=dev)
+    call(ops.conv_kxk, ptr(xh), cin, ptr(wt), ptr(b), ptr(y), cout, H, W, cin, cout, k, s, p, stream())
+    torch.cuda.synchronize()
+    _close(y, nhwc(want), "conv %dx%d s%d" % (k, k, s))
+
+
+def test_tconv2x2(ops):
+    from gpu_util import call, ptr, stream, nhwc
+    dev = "cuda"
+    H, W, cin, cout = 17, 30, 256, 384
+    x = _rand((1, cin, H, W), 1.0, 21).to(dev)
+    w = _rand((cout * 4, cin, 1, 1), 1.0 / cin ** 0.5, 22).to(dev)
+    want = F.pixel_shuffle(F.conv2d(x.float(), w.float()), 2).half()      # SubpelConv2x, layers.py:92-103
+    wt = w[:, :, 0, 0].view(cout, 4, cin).permute(1, 0, 2).contiguous()   # [dy*2+dx][cout][cin]
+    y = torch.zeros((2 * H, 2 * W, cout), dtype=torch.half, device=dev)
+    call(ops.tconv2x2, ptr(nhwc(x)), cin, ptr(wt), ptr(y), cout, H, W, cin, cout, stream())
+    torch.cuda.synchronize()
+    _close(y, nhwc(want), "tconv2x2")
+
+
+@pytest.mark.parametrize("H,W,C", [(17, 30, 384), (5, 7, 64), (68, 120, 256)])
+def test_dwconv3x3(ops, H, W, C):
+    from gpu_util import call, ptr, stream, nhwc
+    dev = "cuda"
+    x = _rand((1, C, H, W), 1.0, 31).to(dev)
+    w = _rand((C, 1, 3, 3), 0.3, 32).to(dev)
+    want = F.conv2d(x.float(), w.float(), None, padding=1, groups=C).half()
+    wt = w[:, 0].permute(1, 2, 0).reshape(9, C).contiguous()
+    y = torch.zeros((H, W, C), dtype=torch.half, device=dev)
+    call(ops.dwconv3x3, ptr(nhwc(x)), C, ptr(wt), ptr(y), C, H, W, C, stream())
+    torch.cuda.synchronize()
+    _close(y, nhwc(want), "dwconv3x3", rtol=1e-3, atol=1e-3)
+
+
+def test_layout_kernels_exact(ops):
+    from gpu_util import call, ptr, stream, nhwc
+    dev = "cuda"
+    H, W = 70, 100                       # pads to 80 x 112
+    x = _rand((1, 3, H, W), 0.3, 41).to(dev)
+    pb, pr = 80 - H, 112 - W
+    xp = F.pad(x, (0, pr, 0, pb), mode="replicate")
+    want = nhwc(F.pixel_unshuffle(xp, 8))
+    out = torch.zeros((10, 14, 192), dtype=torch.half, device=dev)
+    call(ops.pad_unshuffle8, ptr(nhwc(x)), H, W, 3, ptr(out), 10, 14, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    # shuffle8 + clamp is the inverse (on the clamped values)
+    back = torch.zeros((80, 112, 3), dtype=torch.half, device=dev)
+    call(ops.shuffle8, ptr(out), 192, 10, 14, 3, 1, ptr(back), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(back, nhwc(xp.clamp(-0.5, 0.5)))
+    # shuffle2
+    t = _rand((1, 64, 6, 5), 1.0, 42).to(dev)
+    s2 = torch.zeros((12, 10, 16), dtype=torch.half, device=dev)
+    call(ops.shuffle2, ptr(nhwc(t)), 64, 6, 5, 16, ptr(s2), 16, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(s2, nhwc(F.pixel_shuffle(t, 2)))
+    # replicate pad / crop / mul_channel
+    t = _rand((1, 32, 9, 7), 1.0, 43).to(dev)
+    tp = torch.zeros((12, 8, 32), dtype=torch.half, device=dev)
+    call(ops.replicate_pad, ptr(nhwc(t)), 32, 9, 7, 32, 3, 1, ptr(tp), 32, stream())
+    cr = torch.zeros((9, 7, 32), dtype=torch.half, device=dev)
+    call(ops.crop, ptr(tp), 32, 8, ptr(cr), 32, 9, 7, 32, stream())
+    q = (_rand((32,), 0.3, 44) + 1).to(dev)
+    mc = torch.zeros((9, 7, 32), dtype=torch.half, device=dev)
+    call(ops.mul_channel, ptr(cr), 32, ptr(q), ptr(mc), 32, 63, 32, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(tp, nhwc(F.pad(t, (0, 1, 0, 3), mode="replicate")))
+    assert torch.equal(cr, nhwc(t))
+    assert torch.equal(mc, (nhwc(t) * q))
+
+
+def test_round_z_exact(ops):
+    from gpu_util import call, ptr, stream
+    from oracle import symbols_np as orc
+    dev = "cuda"
+    z = torch.cat([_rand((5000,), 30.0, 51), torch.tensor([0.5, -0.5, 1.5, 2.5, -2.5, 63.5, -64.5, 200, -200]).half()])
+    zh = torch.zeros_like(z).to(dev)
+    zi = torch.zeros(z.numel(), dtype=torch.int8, device=dev)
+    call(ops.round_z, ptr(z.to(dev)), ptr(zh), ptr(zi), z.numel(), stream())
+    torch.cuda.synchronize()
+    wh, wi = orc.round_z(z.numpy())
+    assert np.array_equal(zh.cpu().numpy(), wh)
+    assert np.array_equal(zi.cpu().numpy(), wi)
+
+
+@pytest.mark.parametrize("H,W,thres", [(17, 30, 0.15), (8, 8, 0.0), (68, 120, 0.15), (5, 3, 0.15)])
+def test_y_steps_exact(ops, H, W, thres):
+    """4-step masked quantisation + index + compaction (encoder), index + compaction (decoder) and
+    the restore, all bit-exact against the op-by-op numpy restatement of the reference kernels."""
+    from gpu_util import call, ptr, stream
+    from oracle import symbols_np as orc
+    dev = "cuda"
+    C = 256
+    cq = C // 4
+    y = _rand((H, W, C), 6.0, 61)
+    # scales: mix of negative, tiny, in-range and huge values; every fp16 bucket of the table
+    sc = (_rand((H, W, C), 1.0, 62).float().exp() * 0.3).half()
+    sc[0, 0, :8] = torch.tensor([0.0, -1.0, 0.11, 0.1099, 16.0, 17.0, 0.15, 0.1501]).half()
+    mean_list = [_rand((H, W, C), 2.0, 63 + i) for i in range(4)]
+    n = H * W * cq
+    nb = ops.symbol_blocks(n)
+    yd, scd = y.to(dev), sc.to(dev)
+    acc = torch.full((H, W, C), 7.0, dtype=torch.half, device=dev)
+    sym = torch.zeros(n, dtype=torch.int16, device=dev)
+    cond = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
+    comp = torch.zeros(4 * n, dtype=torch.int16, device=dev)
+    totals = torch.zeros(4, dtype=torch.int32, device=dev)
+    masks = orc.get_mask_4x(H, W, C)
+    want_acc = np.zeros((H, W, C), np.float16)
+    want_syms = []
+    keeps = []
+    for step in range(4):
+        md = mean_list[step].to(dev)
+        call(ops.y_step_enc, ptr(yd), C, ptr(scd), C, ptr(md), C, ptr(acc), C, ptr(sym), ptr(cond),
+             ptr(cnt), ptr(comp), ptr(totals), H, W, C, step, thres, stream())
+        torch.cuda.synchronize()
+        y_q, y_hat, s_hat = orc.process_with_mask(y.numpy(), sc.numpy(), mean_list[step].numpy(),
+                                                  masks[step], thres)
+        comb, keep = orc.build_index_enc(orc.fold4(y_q), orc.fold4(s_hat), thres)
+        want_acc = (want_acc + y_hat).astype(np.float16)
+        assert np.array_equal(sym.cpu().numpy(), comb), "symbols step %d" % step
+        want_syms.append(comb[keep])
+        keeps.append(keep)
+        assert np.array_equal(acc.cpu().numpy(), want_acc), "y_hat_so_far step %d" % step
+    tot = totals.cpu().numpy()
+    assert list(tot) == [len(s) for s in want_syms]
+    assert np.array_equal(comp.cpu().numpy()[:tot.sum()], np.concatenate(want_syms))
+
+    # decoder: index + compaction, then restore from the "decoded" symbols
+    idx = torch.zeros(n, dtype=torch.uint8, device=dev)
+    cidx = torch.zeros(4 * n, dtype=torch.uint8, device=dev)
+    totals_d = torch.zeros(4, dtype=torch.int32, device=dev)
+    acc_d = torch.full((H, W, C), -3.0, dtype=torch.half, device=dev)
+    decoded = torch.zeros(4 * n, dtype=torch.int8, device=dev)
+    base = 0
+    for step in range(4):
+        call(ops.y_step_dec_index, ptr(scd), C, ptr(idx), ptr(cond), ptr(cnt), ptr(cidx),
+             ptr(totals_d), H, W, C, step, thres, stream())
+        torch.cuda.synchronize()
+        s_r = orc.fold4(np.where(masks[step], sc.numpy(), np.float16(0)))
+        widx, wkeep = orc.build_index_dec(s_r, thres)
+        assert np.array_equal(idx.cpu().numpy(), widx)
+        assert np.array_equal(wkeep, keeps[step])
+        k = int(totals_d.cpu().numpy()[step])
+        assert k == len(want_syms[step])
+        assert np.array_equal(cidx.cpu().numpy()[base:base + k], (want_syms[step] & 0xff).astype(np.uint8))
+        dec = (want_syms[step] >> 8).astype(np.int8)
+        decoded[base:base + k] = torch.from_numpy(dec).to(dev)
+        md = mean_list[step].to(dev)
+        call(ops.y_step_dec_restore, ptr(decoded), ptr(cond), ptr(cnt), ptr(totals_d), ptr(md), C,
+             ptr(acc_d), C, H, W, C, step, stream())
+        torch.cuda.synchronize()
+        base += k
+    assert np.array_equal(acc_d.cpu().numpy(), want_acc), "decoder y_hat_so_far == encoder's"
