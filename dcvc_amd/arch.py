@@ -1,0 +1,108 @@
+"""Parameter inventory of the DCVC-UF networks (names and shapes of the reference state_dicts).
+
+The codec itself lives in C++ (dcvc_amd/csrc/codec); Python only needs to know which tensors a
+checkpoint must contain so that
+  * ``DMCI`` / ``DMC`` (dcvc_amd/models.py) can hold and validate a reference checkpoint,
+  * synthetic (seeded random) weights of exactly the reference architecture can be generated for
+    tests and benchmarks (there are no checkpoints in the reference tree, checkpoints/.gitkeep).
+
+Structure restated from /root/reference/src/layers/layers.py:128-188 (building blocks) and
+/root/reference/src/models/image_model.py:15-148 (DMCI). Entries: name -> shape.
+"""
+from collections import OrderedDict
+
+QP_NUM = 64                      # common_model.py:135-136
+
+
+def _conv(spec, name, cin, cout, k=1, bias=True, groups=1):
+    spec[name + ".weight"] = (cout, cin // groups, k, k)
+    if bias:
+        spec[name + ".bias"] = (cout,)
+
+
+def depth_conv_block(spec, prefix, cin, cout, dcb2=False, force_adaptor=False):
+    """layers.py:128-159 DepthConvBlock."""
+    if cin != cout or force_adaptor:
+        _conv(spec, prefix + "adaptor", cin, cout)
+    r = 2 if dcb2 else 1
+    _conv(spec, prefix + "dc.0", cout, cout // r)
+    _conv(spec, prefix + "dc.2", cout // r, cout // r, k=3, groups=cout // r)
+    _conv(spec, prefix + "dc.3", cout // r, cout)
+    _conv(spec, prefix + "ffn.0", cout, cout * 4 // r)
+    _conv(spec, prefix + "ffn.2", cout // r, cout)
+
+
+def residual_block_upsample(spec, prefix, cin, cout, dcb2=False):
+    """layers.py:162-173: SubpelConv2x(kernel 1, no bias) + DepthConvBlock."""
+    _conv(spec, prefix + "up.conv.0", cin, cout * 4, bias=False)
+    depth_conv_block(spec, prefix + "conv.", cout, cout, dcb2=dcb2)
+
+
+def residual_block_stride2(spec, prefix, cin, cout, dcb2=False):
+    """layers.py:176-188: pixel_unshuffle(2) + 1x1 conv + DepthConvBlock."""
+    _conv(spec, prefix + "down", cin * 4, cout)
+    depth_conv_block(spec, prefix + "conv.", cout, cout, dcb2=dcb2)
+
+
+def bit_estimator(spec, prefix, channel):
+    """entropy_models.py:78-91."""
+    spec[prefix + "h"] = (QP_NUM, channel, 4)
+    spec[prefix + "b"] = (QP_NUM, channel, 4)
+    spec[prefix + "a"] = (QP_NUM, channel, 3)
+
+
+# ---------------------------------------------------------------------------------------- DMCI
+DMCI_CH_SRC, DMCI_CH_ENC_DEC, DMCI_CH_Y, DMCI_CH_Z = 192, 384, 256, 128   # image_model.py:15-18
+
+
+def dmci_spec():
+    s = OrderedDict()
+    bit_estimator(s, "bit_estimator_z.", DMCI_CH_Z)
+    c, y, z = DMCI_CH_ENC_DEC, DMCI_CH_Y, DMCI_CH_Z
+    # IntraEncoder, image_model.py:50-69
+    depth_conv_block(s, "enc.enc_1.", DMCI_CH_SRC, c)
+    for i in range(6):
+        depth_conv_block(s, "enc.enc_2.%d." % i, c, c)
+    _conv(s, "enc.enc_2.6", c, y, k=3)
+    # IntraHyperEncoder, image_model.py:86-95
+    depth_conv_block(s, "hyper_enc.conv.0.", y, z)
+    residual_block_stride2(s, "hyper_enc.conv.1.", z, z)
+    residual_block_stride2(s, "hyper_enc.conv.2.", z, z)
+    # IntraHyperDecoder, image_model.py:72-83
+    residual_block_upsample(s, "hyper_dec.conv.0.", z, z)
+    residual_block_upsample(s, "hyper_dec.conv.1.", z, z)
+    depth_conv_block(s, "hyper_dec.conv.2.", z, y)
+    # IntraYPriorFusion, image_model.py:112-123
+    depth_conv_block(s, "y_prior_fusion.conv.0.", y, 2 * y)
+    depth_conv_block(s, "y_prior_fusion.conv.1.", 2 * y, 2 * y)
+    depth_conv_block(s, "y_prior_fusion.conv.2.", 2 * y, 2 * y)
+    _conv(s, "y_prior_fusion.conv.3", 2 * y, 2 * y)
+    # image_model.py:136-140
+    _conv(s, "y_spatial_prior_reduction", 2 * y, y)
+    for i in (1, 2, 3):
+        depth_conv_block(s, "y_spatial_prior_adaptor_%d." % i, 2 * y, 2 * y, force_adaptor=True)
+    depth_conv_block(s, "y_spatial_prior.conv.0.", 2 * y, 2 * y)
+    depth_conv_block(s, "y_spatial_prior.conv.1.", 2 * y, 2 * y)
+    depth_conv_block(s, "y_spatial_prior.conv.2.", 2 * y, 2 * y)
+    _conv(s, "y_spatial_prior.conv.3", 2 * y, 2 * y)
+    # IntraDecoder, image_model.py:21-47
+    residual_block_upsample(s, "dec.dec_1.0.", y, c)
+    for i in range(1, 13):
+        depth_conv_block(s, "dec.dec_1.%d." % i, c, c)
+    depth_conv_block(s, "dec.dec_2.", c, DMCI_CH_SRC)
+    # image_model.py:144-147
+    s["q_scale_enc"] = (QP_NUM, c)
+    s["q_scale_dec"] = (QP_NUM, c)
+    s["q_scale_y_enc"] = (QP_NUM, y)
+    s["q_scale_y_dec"] = (QP_NUM, y)
+    return s
+
+
+def param_count(spec):
+    n = 0
+    for shape in spec.values():
+        k = 1
+        for d in shape:
+            k *= d
+        n += k
+    return n

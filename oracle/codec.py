@@ -1,0 +1,240 @@
+"""CPU oracle of the DCVC-UF *inference* path (TEST INFRASTRUCTURE ONLY - never imported by the
+product; see oracle/__init__.py).
+
+Restates, op by op, what the reference's native proxies do (there is no CPU implementation of
+compress()/decompress() in the reference), under the MI355X build's arithmetic
+policy: fp16 NHWC tensors wherever the proxy materialises one, fp32 math inside an op,
+contractions accumulated exactly like the gfx950 matrix core (oracle/nn_oracle.c).
+
+  DepthConvBlock          layers_proxy.cpp:71-101   (forward), :160-206 (weight folding)
+  ResidualBlockWithStride2  layers_proxy.cpp:234-267 (== layers.py:176-188)
+  ResidualBlockUpsample / SubpelConv2x  layers_proxy.cpp:208-232, 269-324 (== layers.py:92-173)
+  DMCI networks           dmci_proxy.cpp:14-294     (== image_model.py:21-123)
+  DMCI compress           dmci_proxy.cpp:296-421, entropy calls :818-845
+  DMCI decompress         dmci_proxy.cpp:423-602, worker :846-871
+  padding / ec_parallel   dmc_common.cpp:31-35, 64-83
+
+Tensors: numpy float16 [H, W, C]. Weights: dict name -> numpy array in PyTorch layout.
+"""
+import numpy as np
+
+from oracle import nn
+from oracle import rans as orc_rans
+from oracle import symbols_np as sym
+
+F16 = np.float16
+MIN_SYMBOLS_PER_STREAM = 32768      # def_const.h:18
+MAX_EC_PARALLEL = 8                 # py_rans.h:15
+
+
+def to_np_state_dict(state_dict):
+    """torch / numpy state_dict -> numpy; floating tensors become fp16 (finalize_model:
+    net.half(), test_video.py:27-29)."""
+    out = {}
+    for k, v in state_dict.items():
+        a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        if a.dtype.kind == "f":
+            a = a.astype(F16)
+        out[k] = a
+    return out
+
+
+def compute_ec_parallel(symbol_count):
+    return max(1, min(MAX_EC_PARALLEL, symbol_count // MIN_SYMBOLS_PER_STREAM))
+
+
+def get_padding_size(h, w, p):
+    nh = (h + p - 1) // p * p
+    nw = (w + p - 1) // p * p
+    return nw - w, nh - h        # right, bottom
+
+
+def replicate_pad(x, pad_b, pad_r):
+    if pad_b == 0 and pad_r == 0:
+        return x
+    return np.pad(x, ((0, pad_b), (0, pad_r), (0, 0)), mode="edge")
+
+
+class Net:
+    """Functional building blocks over a numpy state_dict."""
+
+    def __init__(self, sd):
+        self.sd = sd
+        self._folded = {}
+
+    def has(self, name):
+        return name in self.sd
+
+    def w(self, name):
+        return self.sd[name]
+
+    def conv1x1(self, x, prefix, **kw):
+        return nn.conv1x1(x, self.sd[prefix + "weight"], self.sd.get(prefix + "bias"), **kw)
+
+    def dcb(self, x, p, shortcut=False, q=None, q2=None):
+        """DepthConvBlockProxy::forward, layers_proxy.cpp:71-101."""
+        sd = self.sd
+        out = x
+        if p + "adaptor.weight" in sd:
+            out = self.conv1x1(x, p + "adaptor.")
+        sc = out
+        t = self.conv1x1(out, p + "dc.0.", wsilu=True)
+        t = nn.dwconv3x3(t, sd[p + "dc.2.weight"])
+        if p not in self._folded:
+            self._folded[p] = nn.fold_dw_bias(sd[p + "dc.3.weight"], sd[p + "dc.2.bias"], sd[p + "dc.3.bias"])
+        out = nn.conv1x1(t, sd[p + "dc.3.weight"], self._folded[p], r1=sc)
+        sc_ffn = out
+        t = self.conv1x1(out, p + "ffn.0.", wsilu=True, chunk_add=True)
+        return nn.conv1x1(t, sd[p + "ffn.2.weight"], sd[p + "ffn.2.bias"], r1=sc_ffn,
+                          r2=sc if shortcut else None, q=q, q2=q2)
+
+    def rb_stride2(self, x, p):
+        """pixel_unshuffle(2) + 1x1 (== the folded 2x2 stride-2 conv) + DCB(shortcut)."""
+        w = self.sd[p + "down.weight"]                      # [C', 4C, 1, 1], ch = c*4 + dy*2 + dx
+        cout, c4 = w.shape[0], w.shape[1]
+        w2 = w.reshape(cout, c4 // 4, 2, 2)                 # PyTorch conv layout [C', C, ky, kx]
+        out = nn.conv_kxk(x, w2, self.sd[p + "down.bias"], 2, 2, 0)
+        return self.dcb(out, p + "conv.", shortcut=True)
+
+    def rb_upsample(self, x, p):
+        out = nn.subpel_conv1x1(x, self.sd[p + "up.conv.0.weight"])
+        return self.dcb(out, p + "conv.", shortcut=True)
+
+
+class DMCIOracle:
+    """CPU restatement of DMCIProxy (set_param / compress / decompress)."""
+    CH_Y, CH_Z = 256, 128
+
+    def __init__(self, state_dict, skip_thres, cdf_tables=None):
+        self.sd = to_np_state_dict(state_dict)
+        self.net = Net(self.sd)
+        self.skip_thres = float(skip_thres)
+        self.tables = orc_rans.Tables()
+        if cdf_tables is not None:
+            self.set_cdf(*cdf_tables)
+        self.debug = {}
+
+    def set_cdf(self, z_cdf, z_len, y_cdf, y_len):
+        self.tables.set_cdf(z_cdf, z_len, 0)
+        self.tables.set_cdf(y_cdf, y_len, 1)
+
+    # ---- sub-networks (dmci_proxy.cpp:14-294)
+    def encoder(self, x_unshuffled, qp):
+        n = self.net
+        out = n.dcb(x_unshuffled, "enc.enc_1.", q2=self.sd["q_scale_enc"][qp])
+        for i in range(6):
+            out = n.dcb(out, "enc.enc_2.%d." % i)
+        return nn.conv_kxk(out, self.sd["enc.enc_2.6.weight"], self.sd["enc.enc_2.6.bias"], 3, 2, 1)
+
+    def hyper_encoder(self, y_pad):
+        n = self.net
+        out = n.dcb(y_pad, "hyper_enc.conv.0.")
+        out = n.rb_stride2(out, "hyper_enc.conv.1.")
+        return n.rb_stride2(out, "hyper_enc.conv.2.")
+
+    def hyper_decoder(self, z_hat):
+        n = self.net
+        out = n.rb_upsample(z_hat, "hyper_dec.conv.0.")
+        out = n.rb_upsample(out, "hyper_dec.conv.1.")
+        return n.dcb(out, "hyper_dec.conv.2.")
+
+    def prior_fusion(self, hyper_params):
+        n = self.net
+        out = n.dcb(hyper_params, "y_prior_fusion.conv.0.")
+        out = n.dcb(out, "y_prior_fusion.conv.1.")
+        out = n.dcb(out, "y_prior_fusion.conv.2.")
+        return n.conv1x1(out, "y_prior_fusion.conv.3.")
+
+    def spatial_prior(self, y_hat_so_far, reduced, k):
+        n = self.net
+        cat = np.concatenate([y_hat_so_far, reduced], axis=-1)
+        out = n.dcb(cat, "y_spatial_prior_adaptor_%d." % k)
+        out = n.dcb(out, "y_spatial_prior.conv.0.")
+        out = n.dcb(out, "y_spatial_prior.conv.1.")
+        out = n.dcb(out, "y_spatial_prior.conv.2.")
+        return n.conv1x1(out, "y_spatial_prior.conv.3.")
+
+    def decoder(self, y_hat, qp):
+        n = self.net
+        out = n.rb_upsample(y_hat, "dec.dec_1.0.")
+        for i in range(1, 12):
+            out = n.dcb(out, "dec.dec_1.%d." % i)
+        out = n.dcb(out, "dec.dec_1.12.", q2=self.sd["q_scale_dec"][qp])
+        out = n.dcb(out, "dec.dec_2.")
+        out = nn.pixel_shuffle(out, 8)
+        return np.clip(out, F16(-0.5), F16(0.5)).astype(F16)          # shuffle.cu:53-56
+
+    def _priors(self, z_hat, yH, yW):
+        hyper = self.hyper_decoder(z_hat)
+        params = self.prior_fusion(hyper)[:yH, :yW]                    # crop_hyper_params
+        reduced = self.net.conv1x1(params, "y_spatial_prior_reduction.")
+        return params, reduced
+
+    # ---- DMCIProxy::compress (dmci_proxy.cpp:296-421)
+    def compress(self, x, qp, padding_b=None, padding_r=None):
+        """x: float16 [H, W, 3] in [-0.5, 0.5] (unpadded). Returns dict(bit_stream, x_hat
+        [H16, W16, 3] fp16, ec_parallel)."""
+        H, W, _ = x.shape
+        pr, pb = get_padding_size(H, W, 16)
+        if padding_b is not None:
+            assert (padding_b, padding_r) == (pb, pr)
+        xu = nn.pixel_unshuffle(replicate_pad(x.astype(F16), pb, pr), 8)       # cat_and_pad.cu:7-31
+        y = self.encoder(xu, qp)
+        yH, yW, C = y.shape
+        pr4, pb4 = get_padding_size(yH, yW, 4)
+        z = self.hyper_encoder(replicate_pad(y, pb4, pr4))
+        z_hat, z_i8 = sym.round_z(z)
+        params, reduced = self._priors(z_hat, yH, yW)
+        scales, means = params[..., :C], params[..., C:]
+        y = nn.mul_channel(y, self.sd["q_scale_y_enc"][qp])
+        masks = sym.get_mask_4x(yH, yW, C)
+        y_hat_so_far = None
+        y_syms = []
+        self.debug = dict(y=y, z_i8=z_i8, scales=[], means=[])
+        for k in range(4):
+            self.debug["scales"].append(scales)
+            self.debug["means"].append(means)
+            y_q, y_hat, s_hat = sym.process_with_mask(y, scales, means, masks[k], self.skip_thres)
+            comb, keep = sym.build_index_enc(sym.fold4(y_q), sym.fold4(s_hat), self.skip_thres)
+            y_syms.append(comb[keep])
+            y_hat_so_far = y_hat if y_hat_so_far is None else (y_hat_so_far + y_hat).astype(F16)
+            if k < 3:
+                sp = self.spatial_prior(y_hat_so_far, reduced, k + 1)
+                scales, means = sp[..., :C], sp[..., C:]
+        y_hat = nn.mul_channel(y_hat_so_far, self.sd["q_scale_y_dec"][qp])
+        self.debug["y_hat"] = y_hat
+        # worker(): entropy coding, groups 3,2,1,0 then z (dmci_proxy.cpp:818-845)
+        total = sum(len(s) for s in y_syms)
+        ec = compute_ec_parallel(total)
+        segs = [("y", y_syms[k]) for k in (3, 2, 1, 0)]
+        segs.append(("z", z_i8.reshape(-1), qp * self.CH_Z, self.CH_Z))
+        stream = orc_rans.encode(self.tables, segs, ec)
+        x_hat = self.decoder(y_hat, qp)
+        self.debug["y_syms"] = y_syms
+        return dict(bit_stream=stream.tobytes(), x_hat=x_hat, ec_parallel=ec)
+
+    # ---- DMCIProxy::decompress (dmci_proxy.cpp:423-602)
+    def decompress(self, bit_stream, qp, height, width, ec_parallel):
+        C = self.CH_Y
+        zH, zW = (height + 63) // 64, (width + 63) // 64
+        yH, yW = (height + 15) // 16, (width + 15) // 16
+        dec = orc_rans.Decoder(self.tables, np.frombuffer(bit_stream, dtype=np.uint8), ec_parallel)
+        z_i8 = dec.decode_z(self.CH_Z * zH * zW, qp * self.CH_Z, self.CH_Z).reshape(zH, zW, self.CH_Z)
+        z_hat = z_i8.astype(F16)
+        params, reduced = self._priors(z_hat, yH, yW)
+        scales, means = params[..., :C], params[..., C:]
+        masks = sym.get_mask_4x(yH, yW, C)
+        y_hat_so_far = None
+        for k in range(4):
+            s_r = sym.fold4(np.where(masks[k], scales, F16(0)).astype(F16))
+            idx, keep = sym.build_index_dec(s_r, self.skip_thres)
+            decoded = dec.decode_y(idx[keep])
+            y_q_r = sym.recover(decoded, keep, (yH, yW, C // 4))
+            y_hat = sym.restore_y_4x(y_q_r, means, masks[k])
+            y_hat_so_far = y_hat if y_hat_so_far is None else (y_hat_so_far + y_hat).astype(F16)
+            if k < 3:
+                sp = self.spatial_prior(y_hat_so_far, reduced, k + 1)
+                scales, means = sp[..., :C], sp[..., C:]
+        dec.close()
+        y_hat = nn.mul_channel(y_hat_so_far, self.sd["q_scale_y_dec"][qp])
+        return self.decoder(y_hat, qp)
