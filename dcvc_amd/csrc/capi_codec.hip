@@ -1,0 +1,85 @@
+// C ABI of the picture codecs (include/dcvc_amd_codec.h).
+#include "capi_common.h"
+#include "codec/dmci.h"
+#include "dcvc_amd_codec.h"
+
+#include <cstring>
+
+struct dcvc_dmci {
+    dcvc::DmciCodec codec;
+};
+
+extern "C" {
+
+dcvc_dmci* dcvc_dmci_create(void)
+{
+    dcvc_dmci* c = nullptr;
+    dcvc::guarded([&] { c = new dcvc_dmci(); });
+    return c;
+}
+
+void dcvc_dmci_destroy(dcvc_dmci* c)
+{
+    delete c;
+}
+
+int dcvc_dmci_set_param(dcvc_dmci* c, int n, const char* const* names, const void* const* data,
+                        const int* dtypes, const int* ndims, const int64_t* dims, float skip_thres)
+{
+    return dcvc::guarded([&] {
+        dcvc::ParamStore ps;
+        const int64_t* d = dims;
+        for (int i = 0; i < n; ++i) {
+            ps.add(names[i], data[i], dtypes[i], d, ndims[i]);
+            d += ndims[i];
+        }
+        c->codec.set_param(ps, skip_thres);
+    });
+}
+
+int dcvc_dmci_compress(dcvc_dmci* c, const void* x, int height, int width, int qp, int padding_b,
+                       int padding_r, void* x_hat, void* stream)
+{
+    int ec = -1;
+    const int rc = dcvc::guarded([&] {
+        const int pb = (height + 15) / 16 * 16 - height, pr = (width + 15) / 16 * 16 - width;
+        if (padding_b != pb || padding_r != pr) {
+            throw std::invalid_argument("compress: padding must extend the picture to multiples of 16");
+        }
+        ec = c->codec.compress(static_cast<const dcvc::half_t*>(x), height, width, qp,
+                               static_cast<dcvc::half_t*>(x_hat), static_cast<hipStream_t>(stream));
+    });
+    return rc < 0 ? rc : ec;
+}
+
+int64_t dcvc_dmci_get_stream(dcvc_dmci* c, uint8_t* dst, size_t cap)
+{
+    const auto& s = c->codec.stream_bytes();
+    if (dst != nullptr) std::memcpy(dst, s.data(), s.size() < cap ? s.size() : cap);
+    return static_cast<int64_t>(s.size());
+}
+
+int dcvc_dmci_decompress(dcvc_dmci* c, const uint8_t* bit_stream, size_t nbytes, int qp, int height,
+                         int width, int ec_parallel, void* x_hat, void* stream)
+{
+    return dcvc::guarded([&] {
+        c->codec.decompress(bit_stream, nbytes, qp, height, width, ec_parallel,
+                            static_cast<dcvc::half_t*>(x_hat), static_cast<hipStream_t>(stream));
+    });
+}
+
+int dcvc_dmci_set_use_graphs(dcvc_dmci* c, int on)
+{
+    return dcvc::guarded([&] { c->codec.set_use_graphs(on != 0); });
+}
+
+int64_t dcvc_dmci_debug_read(dcvc_dmci* c, const char* name, void* dst, size_t cap, void* stream)
+{
+    int64_t n = -1;
+    const int rc = dcvc::guarded([&] {
+        n = static_cast<int64_t>(c->codec.debug_read(name, dst, cap, static_cast<hipStream_t>(stream)));
+    });
+    return rc < 0 ? rc : n;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// Building blocks of the DCVC-UF networks on top of the HIP kernels: parameter store, weight
+// preparation (folding / re-layout done once at set_param time) and the forward launch sequences.
+//
+// Reference for WHAT is computed: src/layers/layers.py:92-188 and the proxy classes in
+// src/layers/extensions/inference/layers_proxy.{h,cpp}. The HOW differs: no tensor pool or
+// per-module pre-allocation plan - modules are stateless launch sequences over caller-provided
+// (pointer, leading-dimension) views plus three shared scratch planes, which keeps the working
+// set of a block chain inside the 256 MiB Infinity Cache.
+#pragma once
+
+#include "kernels/ops.h"
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace dcvc {
+
+// ---------------------------------------------------------------- host-side parameter store
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<half_t> h;        // floating tensors, converted to fp16 (finalize_model: net.half())
+    std::vector<int32_t> i;       // integer tensors (CDF tables)
+    int64_t numel() const;
+};
+
+class ParamStore {
+public:
+    // dtype: 0 = fp16, 1 = fp32, 2 = int32; data is HOST memory
+    void add(const std::string& name, const void* data, int dtype, const int64_t* dims, int ndim);
+    const HostTensor& at(const std::string& name) const;
+    bool has(const std::string& name) const { return m_map.count(name) != 0; }
+
+private:
+    std::map<std::string, HostTensor> m_map;
+};
+
+// ---------------------------------------------------------------- device memory
+// Owns every device allocation of a codec instance; freed together.
+class DeviceArena {
+public:
+    DeviceArena() = default;
+    ~DeviceArena();
+    DeviceArena(const DeviceArena&) = delete;
+    DeviceArena& operator=(const DeviceArena&) = delete;
+    void* alloc(size_t bytes);                       // zero-initialised, 256-B aligned
+    half_t* alloc_half(size_t count) { return static_cast<half_t*>(alloc(count * sizeof(half_t))); }
+    half_t* upload(const std::vector<half_t>& host);
+    void release();
+    size_t total_bytes() const { return m_total; }
+
+private:
+    std::vector<void*> m_ptrs;
+    size_t m_total = 0;
+};
+
+// A view of an NHWC activation: `c` channels starting at p, pixel stride ld.
+struct View {
+    half_t* p = nullptr;
+    int ld = 0;
+    int c = 0;
+    View() = default;
+    View(half_t* p_, int ld_, int c_) : p(p_), ld(ld_), c(c_) {}
+    View slice(int c0, int n) const { return View(p + c0, ld, n); }
+};
+
+// Shared scratch for the block-internal tensors (dc.0 out, depthwise out, ffn chunk out).
+struct Scratch {
+    half_t* t1 = nullptr;
+    half_t* t2 = nullptr;
+    half_t* t3 = nullptr;
+    size_t elems = 0;       // capacity of each plane in fp16 elements
+};
+
+// ---------------------------------------------------------------- weights
+struct Conv1x1W {
+    half_t* w = nullptr;    // [cout][cin]
+    half_t* b = nullptr;    // [cout] or null
+    int cin = 0, cout = 0;
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
+};
+
+// layers.py:128-159 DepthConvBlock; layers_proxy.cpp:160-206 for the folding
+struct DcbW {
+    bool has_adaptor = false;
+    Conv1x1W adaptor, dc0, dc3, ffn0, ffn2;
+    half_t* dw = nullptr;   // [9][cdc]
+    int c = 0;              // block width (output channels)
+    int cdc = 0;            // depthwise width (c or c/2)
+    int cffn = 0;           // ffn inner width after chunk-add (c or c/2)
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
+    // y may alias x only when the block has no adaptor and `shortcut` is false
+    void forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut = false,
+                 const half_t* q_fused = nullptr, const half_t* q_after = nullptr) const;
+};
+
+// layers.py:176-188: pixel_unshuffle(2) + 1x1 == 2x2 stride-2 conv (layers_proxy.cpp:263-264)
+struct Stride2W {
+    half_t* w = nullptr;    // [cout][2][2][cin]
+    half_t* b = nullptr;
+    int cin = 0, cout = 0;
+    DcbW block;
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
+    // x: [H][W][cin] -> tmp, y: [H/2][W/2][cout]
+    void forward(View x, View tmp, View y, int H, int W, const half_t* zeros, const Scratch& s,
+                 hipStream_t st) const;
+};
+
+// layers.py:162-173: SubpelConv2x(kernel 1, no bias) == 2x2 stride-2 transposed conv
+struct UpsampleW {
+    half_t* w = nullptr;    // [4][cout][cin]
+    int cin = 0, cout = 0;
+    DcbW block;
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
+    // x: [H][W][cin] -> tmp, y: [2H][2W][cout]
+    void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st) const;
+};
+
+// dense k x k conv weight in tap-major layout
+struct ConvKW {
+    half_t* w = nullptr;    // [cout][k][k][cin]
+    half_t* b = nullptr;
+    int cin = 0, cout = 0, k = 0;
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
+};
+
+}  // namespace dcvc

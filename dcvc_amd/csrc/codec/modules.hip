@@ -1,0 +1,265 @@
+#include "codec/modules.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace dcvc {
+
+// ---------------------------------------------------------------- ParamStore
+int64_t HostTensor::numel() const
+{
+    int64_t n = 1;
+    for (int64_t d : shape) n *= d;
+    return n;
+}
+
+void ParamStore::add(const std::string& name, const void* data, int dtype, const int64_t* dims, int ndim)
+{
+    HostTensor t;
+    t.shape.assign(dims, dims + ndim);
+    const int64_t n = t.numel();
+    if (dtype == 0) {
+        t.h.resize(n);
+        std::memcpy(t.h.data(), data, n * sizeof(half_t));
+    } else if (dtype == 1) {
+        t.h.resize(n);
+        const float* f = static_cast<const float*>(data);
+        for (int64_t i = 0; i < n; ++i) t.h[i] = static_cast<half_t>(f[i]);
+    } else if (dtype == 2) {
+        t.i.resize(n);
+        std::memcpy(t.i.data(), data, n * sizeof(int32_t));
+    } else {
+        throw std::invalid_argument("set_param: unsupported dtype code for " + name);
+    }
+    m_map[name] = std::move(t);
+}
+
+const HostTensor& ParamStore::at(const std::string& name) const
+{
+    auto it = m_map.find(name);
+    if (it == m_map.end()) {
+        throw std::out_of_range("state_dict has no entry '" + name + "'");
+    }
+    return it->second;
+}
+
+// ---------------------------------------------------------------- DeviceArena
+DeviceArena::~DeviceArena()
+{
+    release();
+}
+
+void* DeviceArena::alloc(size_t bytes)
+{
+    void* p = nullptr;
+    const size_t sz = (bytes + 255) / 256 * 256 + 256;
+    hip_check(hipMalloc(&p, sz), "hipMalloc");
+    hip_check(hipMemset(p, 0, sz), "hipMemset");
+    m_ptrs.push_back(p);
+    m_total += sz;
+    return p;
+}
+
+half_t* DeviceArena::upload(const std::vector<half_t>& host)
+{
+    half_t* d = alloc_half(host.size());
+    hip_check(hipMemcpy(d, host.data(), host.size() * sizeof(half_t), hipMemcpyHostToDevice), "upload");
+    return d;
+}
+
+void DeviceArena::release()
+{
+    for (void* p : m_ptrs) (void)hipFree(p);
+    m_ptrs.clear();
+    m_total = 0;
+}
+
+// ---------------------------------------------------------------- weights
+namespace {
+
+void expect_conv(const HostTensor& w, int k, const std::string& name)
+{
+    if (w.shape.size() != 4 || w.shape[2] != k || w.shape[3] != k) {
+        throw std::invalid_argument("unexpected weight shape for " + name);
+    }
+}
+
+}  // namespace
+
+void Conv1x1W::load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix)
+{
+    const HostTensor& wt = ps.at(prefix + "weight");
+    expect_conv(wt, 1, prefix + "weight");
+    cout = static_cast<int>(wt.shape[0]);
+    cin = static_cast<int>(wt.shape[1]);
+    w = mem.upload(wt.h);
+    b = ps.has(prefix + "bias") ? mem.upload(ps.at(prefix + "bias").h) : nullptr;
+}
+
+void ConvKW::load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix)
+{
+    const HostTensor& wt = ps.at(prefix + "weight");     // [cout][cin][k][k]
+    if (wt.shape.size() != 4 || wt.shape[2] != wt.shape[3]) {
+        throw std::invalid_argument("unexpected weight shape for " + prefix + "weight");
+    }
+    cout = static_cast<int>(wt.shape[0]);
+    cin = static_cast<int>(wt.shape[1]);
+    k = static_cast<int>(wt.shape[2]);
+    std::vector<half_t> r(wt.h.size());
+    for (int n = 0; n < cout; ++n)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < k * k; ++t)
+                r[(static_cast<size_t>(n) * k * k + t) * cin + c] = wt.h[(static_cast<size_t>(n) * cin + c) * k * k + t];
+    w = mem.upload(r);
+    b = ps.has(prefix + "bias") ? mem.upload(ps.at(prefix + "bias").h) : nullptr;
+}
+
+void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
+{
+    has_adaptor = ps.has(p + "adaptor.weight");
+    if (has_adaptor) adaptor.load(ps, mem, p + "adaptor.");
+    dc0.load(ps, mem, p + "dc.0.");
+    ffn0.load(ps, mem, p + "ffn.0.");
+    ffn2.load(ps, mem, p + "ffn.2.");
+    c = dc0.cin;
+    cdc = dc0.cout;
+    cffn = ffn0.cout / 4;
+    // depthwise weight [cdc][1][3][3] -> tap major [9][cdc]
+    const HostTensor& dwt = ps.at(p + "dc.2.weight");
+    if (dwt.shape.size() != 4 || dwt.shape[0] != cdc || dwt.shape[1] != 1 || dwt.shape[2] != 3) {
+        throw std::invalid_argument("unexpected depthwise weight shape for " + p + "dc.2.weight");
+    }
+    std::vector<half_t> r(static_cast<size_t>(9) * cdc);
+    for (int ch = 0; ch < cdc; ++ch)
+        for (int t = 0; t < 9; ++t) r[static_cast<size_t>(t) * cdc + ch] = dwt.h[static_cast<size_t>(ch) * 9 + t];
+    dw = mem.upload(r);
+    // dc.3 with the depthwise bias folded through it (layers_proxy.cpp:175-178):
+    //   b' = fp16( fp16( sum_c W3[n][c] * b2[c] ) + b3[n] ), fp32 fmaf chain over c
+    const HostTensor& w3 = ps.at(p + "dc.3.weight");
+    expect_conv(w3, 1, p + "dc.3.weight");
+    const HostTensor& b2 = ps.at(p + "dc.2.bias");
+    const HostTensor& b3 = ps.at(p + "dc.3.bias");
+    dc3.cout = static_cast<int>(w3.shape[0]);
+    dc3.cin = static_cast<int>(w3.shape[1]);
+    dc3.w = mem.upload(w3.h);
+    std::vector<half_t> folded(dc3.cout);
+    for (int n = 0; n < dc3.cout; ++n) {
+        float acc = 0.f;
+        for (int ch = 0; ch < dc3.cin; ++ch) {
+            acc = std::fmaf(static_cast<float>(w3.h[static_cast<size_t>(n) * dc3.cin + ch]),
+                            static_cast<float>(b2.h[ch]), acc);
+        }
+        const half_t t = static_cast<half_t>(acc);
+        folded[n] = static_cast<half_t>(static_cast<float>(t) + static_cast<float>(b3.h[n]));
+    }
+    dc3.b = mem.upload(folded);
+    if (dc3.cin != cdc || dc3.cout != c || ffn0.cin != c || ffn2.cin != cffn || ffn2.cout != c) {
+        throw std::invalid_argument("inconsistent DepthConvBlock shapes under " + p);
+    }
+}
+
+void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut,
+                   const half_t* q_fused, const half_t* q_after) const
+{
+    const int P = H * W;
+    if (static_cast<size_t>(P) * cdc > s.elems || static_cast<size_t>(P) * cffn > s.elems) {
+        throw std::runtime_error("DepthConvBlock: scratch planes too small");
+    }
+    View in = x;
+    if (has_adaptor && shortcut) {
+        // the adaptor output would have to survive the in-place dc.3 / ffn.2 updates
+        throw std::invalid_argument("DepthConvBlock with adaptor and shortcut is not a DCVC-UF block");
+    }
+    if (has_adaptor) {
+        Conv1x1Desc d;
+        d.x = x.p; d.ldx = x.ld; d.w = adaptor.w; d.bias = adaptor.b;
+        d.y = y.p; d.ldy = y.ld; d.pixels = P; d.cin = adaptor.cin; d.cout = adaptor.cout;
+        conv1x1(d, st);
+        in = y;
+    } else if (shortcut && x.p == y.p) {
+        throw std::invalid_argument("DepthConvBlock with shortcut cannot run in place");
+    }
+    {   // dc.0 + WSiLU
+        Conv1x1Desc d;
+        d.x = in.p; d.ldx = in.ld; d.w = dc0.w; d.bias = dc0.b; d.wsilu = true;
+        d.y = s.t1; d.ldy = cdc; d.pixels = P; d.cin = c; d.cout = cdc;
+        conv1x1(d, st);
+    }
+    dwconv3x3(s.t1, cdc, dw, s.t2, cdc, H, W, cdc, st);
+    {   // dc.3 (+ folded depthwise bias) + shortcut
+        Conv1x1Desc d;
+        d.x = s.t2; d.ldx = cdc; d.w = dc3.w; d.bias = dc3.b; d.r1 = in.p; d.ldr1 = in.ld;
+        d.y = y.p; d.ldy = y.ld; d.pixels = P; d.cin = cdc; d.cout = c;
+        conv1x1(d, st);
+    }
+    {   // ffn.0 + WSiLU + chunk-add: the 4x expanded tensor never reaches HBM
+        Conv1x1Desc d;
+        d.x = y.p; d.ldx = y.ld; d.w = ffn0.w; d.bias = ffn0.b; d.wsilu = true; d.chunk_add = true;
+        d.y = s.t3; d.ldy = cffn; d.pixels = P; d.cin = c; d.cout = ffn0.cout;
+        conv1x1(d, st);
+    }
+    {   // ffn.2 + shortcut (+ block input when `shortcut`) (* quant)
+        Conv1x1Desc d;
+        d.x = s.t3; d.ldx = cffn; d.w = ffn2.w; d.bias = ffn2.b; d.r1 = y.p; d.ldr1 = y.ld;
+        if (shortcut) { d.r2 = in.p; d.ldr2 = in.ld; }
+        d.q = q_fused; d.q2 = q_after;
+        d.y = y.p; d.ldy = y.ld; d.pixels = P; d.cin = cffn; d.cout = c;
+        conv1x1(d, st);
+    }
+}
+
+void Stride2W::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
+{
+    const HostTensor& wt = ps.at(p + "down.weight");     // [cout][4*cin][1][1], channel = c*4 + dy*2 + dx
+    expect_conv(wt, 1, p + "down.weight");
+    cout = static_cast<int>(wt.shape[0]);
+    cin = static_cast<int>(wt.shape[1]) / 4;
+    std::vector<half_t> r(wt.h.size());
+    for (int n = 0; n < cout; ++n)
+        for (int ch = 0; ch < cin; ++ch)
+            for (int t = 0; t < 4; ++t)
+                r[(static_cast<size_t>(n) * 4 + t) * cin + ch] = wt.h[static_cast<size_t>(n) * 4 * cin + ch * 4 + t];
+    w = mem.upload(r);
+    b = mem.upload(ps.at(p + "down.bias").h);
+    block.load(ps, mem, p + "conv.");
+}
+
+void Stride2W::forward(View x, View tmp, View y, int H, int W, const half_t* zeros, const Scratch& s,
+                       hipStream_t st) const
+{
+    ConvKxKDesc d;
+    d.x = x.p; d.ldx = x.ld; d.w = w; d.bias = b; d.zeros = zeros;
+    d.y = tmp.p; d.ldy = tmp.ld; d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
+    d.ksize = 2; d.stride = 2; d.pad = 0;
+    conv_kxk(d, st);
+    block.forward(tmp, y, H / 2, W / 2, s, st, /*shortcut=*/true);
+}
+
+void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
+{
+    const HostTensor& wt = ps.at(p + "up.conv.0.weight");   // [4*cout][cin][1][1], row = co*4 + dy*2 + dx
+    expect_conv(wt, 1, p + "up.conv.0.weight");
+    if (ps.has(p + "up.conv.0.bias")) {
+        throw std::invalid_argument("biased SubpelConv2x is not a 2x2 transposed conv: " + p);
+    }
+    cout = static_cast<int>(wt.shape[0]) / 4;
+    cin = static_cast<int>(wt.shape[1]);
+    std::vector<half_t> r(wt.h.size());
+    for (int co = 0; co < cout; ++co)
+        for (int t = 0; t < 4; ++t)
+            std::memcpy(&r[(static_cast<size_t>(t) * cout + co) * cin], &wt.h[(static_cast<size_t>(co) * 4 + t) * cin],
+                        cin * sizeof(half_t));
+    w = mem.upload(r);
+    block.load(ps, mem, p + "conv.");
+}
+
+void UpsampleW::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st) const
+{
+    TConv2x2Desc d;
+    d.x = x.p; d.ldx = x.ld; d.w = w; d.y = tmp.p; d.ldy = tmp.ld;
+    d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
+    tconv2x2(d, st);
+    block.forward(tmp, y, 2 * H, 2 * W, s, st, /*shortcut=*/true);
+}
+
+}  // namespace dcvc

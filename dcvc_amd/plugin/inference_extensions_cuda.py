@@ -1,0 +1,128 @@
+"""Drop-in for the reference's native plugin ``inference_extensions_cuda``
+(/root/reference/src/layers/extensions/inference/bind.cpp:11-39) on MI355X: the same class and
+method names with the same argument meaning, implemented over the C ABI of libdcvc_amd.so
+(include/dcvc_amd_codec.h). The reference imports it lazily by this name
+(src/models/image_model.py:197); put ``dcvc_amd/plugin`` on ``sys.path`` or call
+``dcvc_amd.install_plugin()``.
+
+There is no fallback of any kind: a missing shared object or a failing call raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from dcvc_amd import _lib
+
+_vp, _ci = ctypes.c_void_p, ctypes.c_int
+_F = dict(
+    create=_lib.fn("dcvc_dmci_create", _vp, []),
+    destroy=_lib.fn("dcvc_dmci_destroy", None, [_vp]),
+    set_param=_lib.fn("dcvc_dmci_set_param", _ci,
+                      [_vp, _ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_vp),
+                       ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(ctypes.c_int64),
+                       ctypes.c_float]),
+    compress=_lib.fn("dcvc_dmci_compress", _ci, [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp]),
+    get_stream=_lib.fn("dcvc_dmci_get_stream", ctypes.c_int64, [_vp, _vp, ctypes.c_size_t]),
+    decompress=_lib.fn("dcvc_dmci_decompress", _ci, [_vp, _vp, ctypes.c_size_t, _ci, _ci, _ci, _ci, _vp, _vp]),
+    use_graphs=_lib.fn("dcvc_dmci_set_use_graphs", _ci, [_vp, _ci]),
+    debug_read=_lib.fn("dcvc_dmci_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
+)
+
+_DTYPES = {torch.float16: 0, torch.float32: 1, torch.int32: 2}
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pack_state_dict(state_dict):
+    """state_dict (torch tensors on any device) -> ctypes arrays over host copies."""
+    names, keep, ptrs, dtypes, ndims, dims = [], [], [], [], [], []
+    for name, t in state_dict.items():
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t)
+        if t.dtype == torch.int64:
+            t = t.to(torch.int32)
+        if t.dtype not in _DTYPES:
+            t = t.float()
+        h = t.detach().to("cpu").contiguous()
+        keep.append(h)
+        names.append(name.encode())
+        ptrs.append(h.data_ptr())
+        dtypes.append(_DTYPES[h.dtype])
+        ndims.append(h.dim())
+        dims.extend(h.shape)
+    n = len(names)
+    return (n, (ctypes.c_char_p * n)(*names), (_vp * n)(*ptrs), (_ci * n)(*dtypes), (_ci * n)(*ndims),
+            (ctypes.c_int64 * max(1, len(dims)))(*dims), keep)
+
+
+def _nhwc_ptr(x, channels):
+    """[1, C, H, W] channels_last fp16 CUDA tensor -> pointer to its [H][W][C] memory."""
+    if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != channels:
+        raise ValueError("expected a [1, %d, H, W] tensor, got %s" % (channels, tuple(x.shape)))
+    if x.dtype != torch.float16 or not x.is_cuda:
+        raise ValueError("expected a CUDA fp16 tensor")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    return x, ctypes.c_void_p(x.data_ptr())
+
+
+class DMCIProxy:
+    """bind.cpp:12-16 / dmci_proxy.h:134-150."""
+
+    def __init__(self):
+        self._h = _F["create"]()
+        if not self._h:
+            raise _lib.DcvcError(_lib.lib().dcvc_last_error().decode())
+        self._x_hat = None
+
+    def __del__(self, _destroy=_F["destroy"]):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _destroy(h)
+
+    def set_param(self, state_dict, skip_thres):
+        n, names, ptrs, dtypes, ndims, dims, keep = _pack_state_dict(state_dict)
+        _lib.check(_F["set_param"](self._h, n, names, ptrs, dtypes, ndims, dims, float(skip_thres)))
+        del keep
+
+    def _out_buffer(self, height, width, device):
+        h16, w16 = (height + 15) // 16 * 16, (width + 15) // 16 * 16
+        if self._x_hat is None or tuple(self._x_hat.shape) != (1, 3, h16, w16) or self._x_hat.device != device:
+            # proxy-owned, overwritten by the next call (dmci_proxy.cpp m_x_hat)
+            self._x_hat = torch.empty((1, 3, h16, w16), dtype=torch.float16, device=device).contiguous(
+                memory_format=torch.channels_last)
+        return self._x_hat
+
+    def compress(self, x, qp, padding_b, padding_r):
+        """-> (np.ndarray[uint8] bit stream, x_hat [1, 3, ceil16(H), ceil16(W)], ec_parallel)"""
+        x, xp = _nhwc_ptr(x, 3)
+        height, width = int(x.shape[2]), int(x.shape[3])
+        x_hat = self._out_buffer(height, width, x.device)
+        ec = _lib.check(_F["compress"](self._h, xp, height, width, int(qp), int(padding_b), int(padding_r),
+                                       ctypes.c_void_p(x_hat.data_ptr()), _stream_ptr()))
+        n = _F["get_stream"](self._h, None, 0)
+        out = np.empty(n, dtype=np.uint8)
+        _F["get_stream"](self._h, out.ctypes.data_as(_vp), n)
+        return out, x_hat, int(ec)
+
+    def decompress(self, bit_stream, qp, height, width, entropy_coder_parallel):
+        bs = np.ascontiguousarray(bit_stream, dtype=np.uint8)
+        device = torch.device("cuda", torch.cuda.current_device())
+        x_hat = self._out_buffer(int(height), int(width), device)
+        _lib.check(_F["decompress"](self._h, bs.ctypes.data_as(_vp), bs.size, int(qp), int(height), int(width),
+                                    int(entropy_coder_parallel), ctypes.c_void_p(x_hat.data_ptr()),
+                                    _stream_ptr()))
+        return x_hat
+
+    # ---- not part of the reference surface
+    def set_use_graphs(self, on):
+        _lib.check(_F["use_graphs"](self._h, 1 if on else 0))
+
+    def debug_read(self, name, dtype):
+        n = _lib.check(_F["debug_read"](self._h, name.encode(), None, 0, _stream_ptr()))
+        buf = np.empty(n, dtype=np.uint8)
+        _lib.check(_F["debug_read"](self._h, name.encode(), buf.ctypes.data_as(_vp), n, _stream_ptr()))
+        return buf.view(dtype)

@@ -1,0 +1,66 @@
+/*
+ * dcvc_amd_codec.h - C ABI of the DCVC-UF picture codecs (libdcvc_amd.so).
+ *
+ * Replaces the pybind11 module `inference_extensions_cuda`
+ *   /root/reference/src/layers/extensions/inference/bind.cpp:11-39
+ * (classes DMCIProxy / DMCHTSProxy / DMCHTLProxy / DMCLDProxy with set_param / compress /
+ * decompress / add_ref_feature_from_frame). Tensors cross the boundary as plain pointers:
+ * parameters in HOST memory, pictures as DEVICE pointers to fp16 NHWC ("channels_last") data on
+ * the current HIP device; `stream` is a hipStream_t. Returns 0 (or the documented value) on
+ * success, a negative value on error (message in dcvc_last_error()).
+ */
+#ifndef DCVC_AMD_CODEC_H
+#define DCVC_AMD_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dcvc_dmci dcvc_dmci;
+
+/* tensor element types of dcvc_*_set_param */
+#define DCVC_F16 0
+#define DCVC_F32 1
+#define DCVC_I32 2
+
+/* bind.cpp:12-16  DMCIProxy() */
+dcvc_dmci* dcvc_dmci_create(void);
+void dcvc_dmci_destroy(dcvc_dmci* c);
+
+/* DMCIProxy.set_param(state_dict, skip_thres), dmci_proxy.cpp:604-652.
+ * n tensors: names[i], data[i] (host memory), dtypes[i] (DCVC_*), ndims[i], and their dims
+ * concatenated in `dims`. The state_dict is the module's state_dict() plus the four int32 CDF
+ * tensors gaussian_encoder.{quantized_cdf,cdf_length}, bit_estimator_z.{quantized_cdf,cdf_length}
+ * (common_model.py:64-70). Everything is copied. */
+int dcvc_dmci_set_param(dcvc_dmci* c, int n, const char* const* names, const void* const* data,
+                        const int* dtypes, const int* ndims, const int64_t* dims, float skip_thres);
+
+/* DMCIProxy.compress(x, qp, padding_b, padding_r) -> (bit_stream, x_hat, ec_parallel),
+ * dmci_proxy.cpp:296-421. x: device fp16 [height][width][3] in [-0.5, 0.5], unpadded;
+ * x_hat: device fp16 [ceil16(height)][ceil16(width)][3], written on `stream` (the call returns
+ * when the bit stream is ready; reconstruction kernels may still be in flight, as in the
+ * reference). padding_b / padding_r must equal the padding to a multiple of 16.
+ * Returns ec_parallel (1..8); the bytes are fetched with dcvc_dmci_get_stream. */
+int dcvc_dmci_compress(dcvc_dmci* c, const void* x, int height, int width, int qp, int padding_b,
+                       int padding_r, void* x_hat, void* stream);
+/* size query (dst == NULL) or copy of at most cap bytes; returns the stream size */
+int64_t dcvc_dmci_get_stream(dcvc_dmci* c, uint8_t* dst, size_t cap);
+
+/* DMCIProxy.decompress(bit_stream, qp, height, width, ec_parallel) -> x_hat,
+ * dmci_proxy.cpp:423-602. */
+int dcvc_dmci_decompress(dcvc_dmci* c, const uint8_t* bit_stream, size_t nbytes, int qp, int height,
+                         int width, int ec_parallel, void* x_hat, void* stream);
+
+/* Not part of the reference surface: 1 = replay the stages as hipGraphs (default), 0 = eager. */
+int dcvc_dmci_set_use_graphs(dcvc_dmci* c, int on);
+/* Test hook: copy an internal tensor of the last call ("y", "y_hat", "z_i8", "params",
+ * "unshuffled", "features", "totals", "symbols") to host memory; returns its size in bytes. */
+int64_t dcvc_dmci_debug_read(dcvc_dmci* c, const char* name, void* dst, size_t cap, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCVC_AMD_CODEC_H */

@@ -1,0 +1,45 @@
+"""Shared helpers of the codec tests."""
+import numpy as np
+import torch
+
+from dcvc_amd import arch, models, synthetic
+
+_CACHE = {}
+
+
+def dmci_model(seed=0, skip_thres=0.0):
+    """Seeded synthetic DMCI (CPU, fp32 parameters) with its CDF tables built."""
+    key = (seed, skip_thres)
+    if key not in _CACHE:
+        m = models.DMCI()
+        m.load_state_dict(synthetic.synthetic_state_dict(arch.dmci_spec(), seed))
+        m.update(skip_thres)
+        _CACHE[key] = m
+    return _CACHE[key]
+
+
+def oracle_for(model):
+    from oracle import codec
+    return codec.DMCIOracle(model.state_dict(), model.skip_thres, model.get_cdf_info())
+
+
+def picture(height, width, index=0, seed=0):
+    """Synthetic YUV420 picture as fp16 [H, W, 3] in [-0.5, 0.5] (nearest chroma upsampling)."""
+    y, uv = synthetic.synthetic_frame_yuv420(height + height % 2, width + width % 2, index, seed)
+    x = synthetic.yuv420_to_x(y, uv)[:, :, :height, :width]
+    return x[0].permute(1, 2, 0).contiguous().numpy().astype(np.float16)
+
+
+def to_device_input(x_hwc):
+    """[H, W, 3] fp16 numpy -> [1, 3, H, W] channels_last CUDA tensor (test_video.py:114-123)."""
+    t = torch.from_numpy(x_hwc).permute(2, 0, 1).unsqueeze(0).cuda()
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def from_device_output(x_hat):
+    return x_hat[0].permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float("inf") if mse == 0 else 10 * np.log10(1.0 / mse)

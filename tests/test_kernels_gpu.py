@@ -91,6 +91,17 @@ def test_conv1x1(ops, case):
         want = (want.float() * q2.float()).half()
     _close(yw[:, :nout], want, "conv1x1 " + case["name"])
     assert torch.count_nonzero(yw[:, nout:]).item() == 0, "wrote outside the channel slice"
+    # bit-exact against the oracle (measured matrix-core arithmetic, oracle/nn_oracle.c)
+    from oracle import nn
+    np_ = lambda t: None if t is None else t.cpu().numpy()
+    rows = slice(0, min(P, 640))
+    orc = nn.conv1x1(np_(x)[rows], np_(w), np_(b), r1=None if r1 is None else np_(r1)[rows],
+                     r2=None if r2 is None else np_(r2)[rows], q=np_(q), q2=np_(q2),
+                     wsilu=bool(case.get("wsilu")), chunk_add=bool(case.get("chunk")))
+    got = yw[rows, :nout].cpu().numpy()
+    bad = int((got != orc).sum())
+    print("   vs oracle: %d mismatching of %d" % (bad, got.size))
+    assert bad == 0
 
 
 @pytest.mark.parametrize("k,s,p,H,W,cin,cout", [(3, 2, 1, 18, 30, 128, 128), (2, 2, 0, 34, 60, 64, 128),
@@ -109,6 +120,9 @@ def test_conv_kxk(ops, k, s, p, H, W, cin, cout):
     call(ops.conv_kxk, ptr(xh), cin, ptr(wt), ptr(b), ptr(y), cout, H, W, cin, cout, k, s, p, stream())
     torch.cuda.synchronize()
     _close(y, nhwc(want), "conv %dx%d s%d" % (k, k, s))
+    from oracle import nn
+    orc = nn.conv_kxk(xh.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), k, s, p)
+    assert np.array_equal(y.cpu().numpy(), orc)
 
 
 def test_tconv2x2(ops):
@@ -123,6 +137,8 @@ def test_tconv2x2(ops):
     call(ops.tconv2x2, ptr(nhwc(x)), cin, ptr(wt), ptr(y), cout, H, W, cin, cout, stream())
     torch.cuda.synchronize()
     _close(y, nhwc(want), "tconv2x2")
+    from oracle import nn
+    assert np.array_equal(y.cpu().numpy(), nn.subpel_conv1x1(nhwc(x).cpu().numpy(), w.cpu().numpy()))
 
 
 @pytest.mark.parametrize("H,W,C", [(17, 30, 384), (5, 7, 64), (68, 120, 256)])
@@ -137,6 +153,8 @@ def test_dwconv3x3(ops, H, W, C):
     call(ops.dwconv3x3, ptr(nhwc(x)), C, ptr(wt), ptr(y), C, H, W, C, stream())
     torch.cuda.synchronize()
     _close(y, nhwc(want), "dwconv3x3", rtol=1e-3, atol=1e-3)
+    from oracle import nn
+    assert np.array_equal(y.cpu().numpy(), nn.dwconv3x3(nhwc(x).cpu().numpy(), w.cpu().numpy()))
 
 
 def test_layout_kernels_exact(ops):
