@@ -51,6 +51,8 @@ private:
     };
 
     void prepare(int height, int width);
+    hipStream_t enter(hipStream_t user);
+    void leave(hipStream_t user);
     void select_qp(int qp, hipStream_t st);
     // network stages
     void run_encoder(hipStream_t st);                       // U -> Y
@@ -115,7 +117,8 @@ private:
     RansEncoder m_enc;
     RansDecoder m_dec;
     hipStream_t m_io_stream = nullptr;
-    hipEvent_t m_ev_y = nullptr;
+    hipStream_t m_cs = nullptr;           // the codec's compute stream
+    hipEvent_t m_ev_y = nullptr, m_ev_in = nullptr, m_ev_out = nullptr;
     std::thread m_worker;
     std::mutex m_mu;
     std::condition_variable m_cv_work, m_cv_done;

@@ -24,7 +24,10 @@ DmciCodec::DmciCodec()
     int lo = 0, hi = 0;
     hip_check(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
     hip_check(hipStreamCreateWithPriority(&m_io_stream, hipStreamNonBlocking, hi), "hipStreamCreate(io)");
+    hip_check(hipStreamCreateWithFlags(&m_cs, hipStreamNonBlocking), "hipStreamCreate(compute)");
     hip_check(hipEventCreateWithFlags(&m_ev_y, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&m_ev_in, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&m_ev_out, hipEventDisableTiming), "hipEventCreate");
     m_worker = std::thread(&DmciCodec::worker_loop, this);
 }
 
@@ -43,6 +46,9 @@ DmciCodec::~DmciCodec()
     if (m_h_idx) (void)hipHostFree(m_h_idx);
     if (m_h_dec) (void)hipHostFree(m_h_dec);
     if (m_ev_y) (void)hipEventDestroy(m_ev_y);
+    if (m_ev_in) (void)hipEventDestroy(m_ev_in);
+    if (m_ev_out) (void)hipEventDestroy(m_ev_out);
+    if (m_cs) (void)hipStreamDestroy(m_cs);
     if (m_io_stream) (void)hipStreamDestroy(m_io_stream);
 }
 
@@ -325,13 +331,34 @@ void DmciCodec::enc_stage0(hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------ compress
-int DmciCodec::compress(const half_t* x, int height, int width, int qp, half_t* x_hat, hipStream_t st)
+// All codec work runs on the codec's own non-blocking stream, ordered after the caller's stream
+// on entry and before it on exit: graph capture then works whatever stream the caller is on
+// (the legacy default stream cannot capture - the reference harness has to switch streams for
+// that reason, test_video.py:422-425).
+hipStream_t DmciCodec::enter(hipStream_t user)
+{
+    hip_check(hipEventRecord(m_ev_in, user), "hipEventRecord(in)");
+    hip_check(hipStreamWaitEvent(m_cs, m_ev_in, 0), "hipStreamWaitEvent(in)");
+    return m_cs;
+}
+
+void DmciCodec::leave(hipStream_t user)
+{
+    hip_check(hipEventRecord(m_ev_out, m_cs), "hipEventRecord(out)");
+    hip_check(hipStreamWaitEvent(user, m_ev_out, 0), "hipStreamWaitEvent(out)");
+}
+
+int DmciCodec::compress(const half_t* x, int height, int width, int qp, half_t* x_hat, hipStream_t user)
 {
     prepare(height, width);
+    hipStream_t st = enter(user);
     select_qp(qp, st);
     pad_unshuffle8(x, height, width, 3, m_U, m_g.H8, m_g.W8, st);   // outside the graph: x varies
     run_stage(kEnc0, st, [&] { enc_stage0(st); });
     hip_check(hipEventRecord(m_ev_y, st), "hipEventRecord");
+    // the io stream's dependency on the symbols is enqueued here, before the next stage may put
+    // the compute stream into capture mode (HIP refuses cross-stream waits on a capturing stream)
+    hip_check(hipStreamWaitEvent(m_io_stream, m_ev_y, 0), "hipStreamWaitEvent");
     {
         std::lock_guard<std::mutex> lk(m_mu);
         m_pending = true;
@@ -350,6 +377,7 @@ int DmciCodec::compress(const half_t* x, int height, int width, int qp, half_t* 
         slot.arg = x_hat;
     }
     run_stage(kEnc1, st, [&] { run_decoder(x_hat, st); });
+    leave(user);
     std::unique_lock<std::mutex> lk(m_mu);
     m_cv_done.wait(lk, [&] { return m_done; });
     if (!m_worker_error.empty()) throw std::runtime_error("entropy worker: " + m_worker_error);
@@ -386,7 +414,6 @@ void DmciCodec::entropy_encode(int qp)
 {
     // dmci_proxy.cpp:809-845: wait for the symbols, copy them out, code groups 3,2,1,0 then z
     const Geometry& g = m_g;
-    hip_check(hipStreamWaitEvent(m_io_stream, m_ev_y, 0), "hipStreamWaitEvent");
     hip_check(hipMemcpyAsync(m_h_totals, m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, m_io_stream), "D2H totals");
     const int nz = g.P64() * kChZ;
     hip_check(hipMemcpyAsync(m_h_z, m_ZI8, nz, hipMemcpyDeviceToHost, m_io_stream), "D2H z");
@@ -410,10 +437,11 @@ void DmciCodec::entropy_encode(int qp)
 
 // ------------------------------------------------------------------------------------ decompress
 void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int height, int width,
-                           int ec_parallel, half_t* x_hat, hipStream_t st)
+                           int ec_parallel, half_t* x_hat, hipStream_t user)
 {
     prepare(height, width);
     const Geometry& g = m_g;
+    hipStream_t st = enter(user);
     select_qp(qp, st);
     m_dec.set_parallel(ec_parallel);
     m_dec.set_stream(bits, nbytes);
@@ -472,6 +500,7 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
             }
         });
     }
+    leave(user);
 }
 
 // ------------------------------------------------------------------------------------ debug
@@ -491,6 +520,7 @@ size_t DmciCodec::debug_read(const std::string& name, void* dst, size_t cap, hip
     else throw std::invalid_argument("unknown debug tensor '" + name + "'");
     if (dst != nullptr) {
         hip_check(hipStreamSynchronize(st), "sync");
+        hip_check(hipStreamSynchronize(m_cs), "sync");
         hip_check(hipMemcpy(dst, src, std::min(bytes, cap), hipMemcpyDeviceToHost), "debug D2H");
     }
     return bytes;
