@@ -174,4 +174,19 @@ int dcvc_y_step_dec_restore(const void* decoded, const void* cond, const void* b
     });
 }
 
+int dcvc_gemm_profile_enable(int on)
+{
+    return dcvc::guarded([&] { dcvc::gemm_profile_enable(on != 0); });
+}
+
+int dcvc_gemm_profile_reset(void)
+{
+    return dcvc::guarded([&] { dcvc::gemm_profile_reset(); });
+}
+
+int dcvc_gemm_profile_collect(double* ms, double* flops, long long* launches)
+{
+    return dcvc::guarded([&] { dcvc::gemm_profile_collect(ms, flops, launches); });
+}
+
 }  // extern "C"

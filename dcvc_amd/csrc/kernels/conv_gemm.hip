@@ -35,6 +35,8 @@
 
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <vector>
 
 namespace dcvc {
 
@@ -291,9 +293,42 @@ conv_gemm_kernel(const ConvGemmParams p)
     }
 }
 
+// ---- optional per-launch timing (bench.py's roofline leg)
+struct GemmProfile {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<double> flops;
+    size_t used = 0;
+};
+
+GemmProfile& profile()
+{
+    static GemmProfile g;
+    return g;
+}
+
 template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
 void launch(const ConvGemmParams& p, hipStream_t stream)
 {
+    GemmProfile& pf = profile();
+    hipEvent_t ev_stop = nullptr;
+    if (pf.on) {
+        if (pf.used == pf.events.size()) {
+            hipEvent_t a, b;
+            hip_check(hipEventCreate(&a), "hipEventCreate");
+            hip_check(hipEventCreate(&b), "hipEventCreate");
+            pf.events.emplace_back(a, b);
+            pf.flops.push_back(0.0);
+        }
+        pf.flops[pf.used] = 2.0 * p.M * p.N * p.K;
+        hip_check(hipEventRecord(pf.events[pf.used].first, stream), "hipEventRecord");
+        ev_stop = pf.events[pf.used].second;
+        ++pf.used;
+    }
+    struct Stop {
+        hipEvent_t e; hipStream_t s;
+        ~Stop() { if (e) (void)hipEventRecord(e, s); }
+    } stop{ ev_stop, stream };
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     auto kern = conv_gemm_kernel<SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>;
     static bool attr_set = false;
@@ -323,6 +358,32 @@ void check_common(const ConvGemmParams& p)
 }
 
 }  // namespace
+
+void gemm_profile_enable(bool on)
+{
+    profile().on = on;
+}
+
+void gemm_profile_reset()
+{
+    profile().used = 0;
+}
+
+void gemm_profile_collect(double* ms, double* flops, long long* launches)
+{
+    GemmProfile& pf = profile();
+    double t = 0, f = 0;
+    for (size_t i = 0; i < pf.used; ++i) {
+        hip_check(hipEventSynchronize(pf.events[i].second), "hipEventSynchronize");
+        float e = 0.f;
+        hip_check(hipEventElapsedTime(&e, pf.events[i].first, pf.events[i].second), "hipEventElapsedTime");
+        t += e;
+        f += pf.flops[i];
+    }
+    *ms = t;
+    *flops = f;
+    *launches = static_cast<long long>(pf.used);
+}
 
 // ------------------------------------------------------------------------------------------
 // public launchers (ops.h)

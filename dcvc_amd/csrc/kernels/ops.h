@@ -20,6 +20,14 @@ inline void hip_check(hipError_t e, const char* what)
     }
 }
 
+// ---------------------------------------------------------------- per-kernel timing (conv_gemm.hip)
+// When enabled, every contraction launch is bracketed by a pair of HIP events on its own stream
+// (launches must then be eager, not captured). collect() synchronises the events and returns
+// the summed kernel time, the algorithmic FLOPs (2*M*N*K) and the launch count since reset().
+void gemm_profile_enable(bool on);
+void gemm_profile_reset();
+void gemm_profile_collect(double* ms, double* flops, long long* launches);
+
 // ---------------------------------------------------------------- dense convolutions (conv_gemm.hip)
 struct Conv1x1Desc {
     const half_t* x = nullptr; int ldx = 0;     // [pixels][ldx], first `cin` channels of each pixel

@@ -79,6 +79,13 @@ int dcvc_y_step_dec_restore(const void* decoded, const void* cond, const void* b
                             const void* totals, const void* means, int ldm,
                             void* y_hat_acc, int ldacc, int H, int W, int C, int step, void* stream);
 
+/* Measurement hook (bench.py roofline leg, not a reference entry point): bracket every
+ * contraction launch with HIP events on its stream; collect = summed kernel milliseconds,
+ * algorithmic FLOPs (2*M*N*K) and launch count since the last reset. Graph replay must be off. */
+int dcvc_gemm_profile_enable(int on);
+int dcvc_gemm_profile_reset(void);
+int dcvc_gemm_profile_collect(double* ms, double* flops, long long* launches);
+
 #ifdef __cplusplus
 }
 #endif

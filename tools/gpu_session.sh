@@ -1,0 +1,11 @@
+#!/bin/bash
+# One gpurun session: tests, smoke, bench, rocprof kernel trace. Outputs under gpurun_out/.
+set -x
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/test_gpu.log
+python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
+python bench.py --steps 30 --warmup 8 > gpurun_out/bench.log 2>&1
+tail -3 gpurun_out/bench.log
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py --steps 10 --warmup 4 --no-cpu-baseline > gpurun_out/bench_prof.log 2>&1
+ls -R gpurun_out/prof | head -20

@@ -1,26 +1,30 @@
-"""smoke(): one tiny invocation of the hot path on cuda:0, checked against the oracle."""
-import ctypes
+"""smoke(): one small invocation of the hot path on cuda:0, checked against the oracle:
+DMCI compress + decompress of a 64x64 picture through the reference's plugin surface; the rANS
+bytes and the reconstruction must equal the CPU oracle's bit for bit."""
+import copy
+import os
+import sys
 
 import numpy as np
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
 
 def run():
-    from dcvc_amd import _lib
-    # fused 1x1 conv + bias + WSiLU on the matrix cores vs fp32 torch
-    vp, ci = ctypes.c_void_p, ctypes.c_int
-    conv = _lib.fn("dcvc_conv1x1", ci, [vp, ci, vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp])
-    g = torch.Generator().manual_seed(0)
-    P, K, N = 300, 128, 128
-    x = torch.randn((P, K), generator=g).half().cuda()
-    w = (torch.randn((N, K), generator=g) / K ** 0.5).half().cuda()
-    b = torch.randn((N,), generator=g).half().cuda()
-    y = torch.zeros((P, N), dtype=torch.half, device="cuda")
-    _lib.check(conv(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), None, 0, None, 0, None, None,
-                    y.data_ptr(), N, P, K, N, 1, None))
+    from codec_util import dmci_model, from_device_output, oracle_for, picture, to_device_input
+    m = dmci_model(skip_thres=0.15)
+    g = copy.deepcopy(m).half().cuda()
+    g.proxy = None
+    x = picture(64, 64)
+    got = g.compress(to_device_input(x), 32, 0, 0)
     torch.cuda.synchronize()
-    acc = x.float() @ w.float().t() + b.float()
-    want = (acc * torch.sigmoid(4 * acc)).half()
-    err = (y.float() - want.float()).abs().max().item()
-    assert err < 5e-3, err
-    print("smoke ok: conv1x1+bias+wsilu max abs err %.2e" % err)
+    want = oracle_for(m).compress(x, 32)
+    assert got["bit_stream"] == want["bit_stream"], "bit stream differs from the oracle"
+    assert np.array_equal(from_device_output(got["x_hat"]), want["x_hat"]), "x_hat differs from the oracle"
+    dec = g.decompress(got["bit_stream"], {"height": 64, "width": 64}, 32, got["ec_parallel"])
+    torch.cuda.synchronize()
+    assert torch.equal(dec["x_hat"], got["x_hat"])
+    print("smoke ok: DMCI 64x64 qp32 -> %d bytes, bit-exact vs oracle, decode closure ok"
+          % len(got["bit_stream"]))
