@@ -118,6 +118,22 @@ def roofline(gpu_net, pics, pad_b, pad_r):
     torch.cuda.synchronize()
     ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
     _lib.check(co(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ln)))
+    if os.environ.get("DCVC_BENCH_SHAPES"):
+        rec = np.dtype([("M", np.int32), ("N", np.int32), ("K", np.int32), ("variant", np.int32), ("ms", np.float32)])
+        buf = np.zeros(int(ln.value), dtype=rec)
+        _lib.fn("dcvc_gemm_profile_launches", ctypes.c_longlong, [ctypes.c_void_p, ctypes.c_longlong])(
+            buf.ctypes.data, len(buf))
+        agg = {}
+        for r in buf:
+            k = (int(r["M"]), int(r["N"]), int(r["K"]), int(r["variant"]))
+            a = agg.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["ms"])
+        with open(os.environ["DCVC_BENCH_SHAPES"], "w") as f:
+            f.write("M,N,K,variant,calls_per_step,avg_us,tflops,ms_per_step\n")
+            for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write("%d,%d,%d,%d,%.1f,%.2f,%.1f,%.3f\n" % (
+                    k + (a[0] / n, 1e3 * a[1] / a[0], 2.0 * k[0] * k[1] * k[2] / (a[1] / a[0] * 1e-3) / 1e12, a[1] / n)))
     _lib.check(en(0))
     gpu_net.proxy.set_use_graphs(True)
     achieved = fl.value / (ms.value * 1e-3) / 1e12

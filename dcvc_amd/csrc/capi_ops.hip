@@ -36,6 +36,7 @@ int dcvc_conv1x1(const void* x, int ldx, const void* w, const void* bias, const 
         d.r1 = H(r1); d.ldr1 = ldr1; d.r2 = H(r2); d.ldr2 = ldr2;
         d.q = H(q); d.q2 = H(q2); d.y = H(y); d.ldy = ldy;
         d.pixels = pixels; d.cin = cin; d.cout = cout;
+        dcvc::kernels_init();
         d.wsilu = (flags & DCVC_CONV_WSILU) != 0;
         d.chunk_add = (flags & DCVC_CONV_CHUNK_ADD) != 0;
         dcvc::conv1x1(d, S(stream));
@@ -187,6 +188,16 @@ int dcvc_gemm_profile_reset(void)
 int dcvc_gemm_profile_collect(double* ms, double* flops, long long* launches)
 {
     return dcvc::guarded([&] { dcvc::gemm_profile_collect(ms, flops, launches); });
+}
+
+long long dcvc_gemm_profile_launches(void* records, long long cap)
+{
+    long long n = -1;
+    dcvc::guarded([&] {
+        n = static_cast<long long>(dcvc::gemm_profile_launches(static_cast<dcvc::GemmLaunchInfo*>(records),
+                                                                 static_cast<size_t>(cap)));
+    });
+    return n;
 }
 
 }  // extern "C"

@@ -65,7 +65,7 @@ void DmciCodec::set_param(const ParamStore& ps, float skip_thres)
 {
     clear_graphs();
     m_wmem.release();
-    symbols_init();
+    kernels_init();
     m_skip_thres = skip_thres;
     auto table = [&](const char* name, int ch) {
         const HostTensor& t = ps.at(name);

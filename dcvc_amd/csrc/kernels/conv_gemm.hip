@@ -17,9 +17,10 @@
 //     the "B" operand of v_mfma_f32_32x32x16_f16, so a lane's 16 accumulators are 4 groups of 4
 //     CONSECUTIVE output channels of ONE pixel. chunk-add (sum of 4 adjacent channels) is then a
 //     purely in-register reduction and the NHWC store is channel-contiguous.
-//   * 128(pixels) x 128(channels) x 64(k) block tile, 4 waves (2x2), each wave 64x64 =
-//     2x2 MFMA tiles; fp32 accumulation, k ascending in steps of 16 (fixed order -> results do
-//     not depend on the tile shape; the oracle restates the same order).
+//   * block tile (WM*MT*32 pixels) x (WN*NT*32 channels) x 64 k, WM x WN waves each owning
+//     MT x NT MFMA tiles; fp32 accumulation, k ascending in steps of 16 (fixed order -> results
+//     do not depend on the tile shape; the oracle restates the same order). Shapes in use:
+//     128x128 (4 waves), 64x128 (4 waves, small pictures / P16 layers), chosen per launch.
 //   * global -> LDS staging by global_load_lds (16 B per lane, no VGPR round trip), two LDS
 //     stages, one barrier per k-step. The LDS image is lane-linear, so the bank-conflict swizzle
 //     (16-B chunk index XOR ((row >> 1) & 7)) is applied to the per-lane SOURCE address and to
@@ -28,11 +29,16 @@
 //     are first-class (the reference's free torch.cat, conv1x1_kernel.h:82,102-107).
 //   * epilogue straight from the accumulators: v_permlane32_swap pairs the two half-waves so
 //     each lane owns 8 consecutive channels -> 16-B bias / residual loads and 16-B stores.
+//     WSiLU is a 4 KiB piecewise-cubic table in LDS (arith.h).
 //   * XCD-aware block order: consecutive logical tiles (same pixel rows, adjacent channel tiles)
 //     run on the same XCD and share the activation tile in that XCD's L2.
 #include "arith.h"
 #include "ops.h"
+#include "wsilu_table.h"
 
+#include <hip/hip_ext.h>
+
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -42,11 +48,8 @@ namespace dcvc {
 
 namespace {
 
-constexpr int BM = 128;            // pixels per block tile
-constexpr int BN = 128;            // output channels (pre chunk-add) per block tile
 constexpr int BK = 64;             // k per stage
-constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB, same for the activation and the weight tile
-constexpr int NTHREADS = 256;
+constexpr int WSILU_TABLE_BYTES = WSILU_SEGMENTS * 16;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -61,6 +64,7 @@ struct ConvGemmParams {
     const half_t* q2;     // second per-channel scale applied to the ROUNDED output (models the
                           // reference's separate multiply_with_broadcast kernel) or nullptr
     const half_t* zeros;  // >= 128 B of zeros (padding taps)
+    const float4* wsilu;  // WSiLU coefficient table (device memory)
     half_t* y;            // output, pixel stride ldy
     int ldx, ldr1, ldr2, ldy;
     int M, N, K;          // output pixels, output channels (pre chunk-add), contraction length
@@ -92,16 +96,28 @@ __device__ __forceinline__ const half_t* x_row_ptr(const ConvGemmParams& p, int 
     }
 }
 
-template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
-__global__ void __launch_bounds__(NTHREADS, 2)
+template <int WM, int WN, int MT, int NT, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+__global__ void __launch_bounds__(WM * WN * 64)
 conv_gemm_kernel(const ConvGemmParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (X tile, W tile)
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    constexpr int XT_BYTES = BM * BK * 2;
+    constexpr int WT_BYTES = BN * BK * 2;
+    constexpr int STAGE_BYTES = XT_BYTES + WT_BYTES;
+    constexpr int XU = BM * 8 / NTHREADS;      // 16-B units per thread and stage
+    constexpr int WU = BN * 8 / NTHREADS;
+    constexpr int ROWS_PER_PASS = NTHREADS / 8;
+    static_assert(ROWS_PER_PASS % 16 == 0, "swizzle term must not depend on the pass");
+    static_assert(!CHUNK || NT % 2 == 0, "chunk-add pairs two channel tiles");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (X tile, W tile) [+ table]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5;
 
     // ---- XCD-aware tile order (bijective chunking: XCD x gets a contiguous range of tiles)
@@ -117,28 +133,29 @@ conv_gemm_kernel(const ConvGemmParams p)
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
 
-    // ---- staging plan: thread t moves 16-B unit u = j*256 + t of each tile, j = 0..3
+    // ---- staging plan: thread t moves 16-B unit u = j*NTHREADS + t of each tile
     //      unit u -> row u>>3, physical chunk u&7; logical chunk = physical ^ ((row>>1)&7)
-    const int srow = tid >> 3;                       // 0..31 (+32 j)
+    const int srow = tid >> 3;
     const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-    int xrow[4];
-    const half_t* wsrc[4];
+    int xrow[XU];
+    const half_t* wsrc[WU];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = j * 32 + srow;
-        xrow[j] = min(m0 + r, p.M - 1);
-        wsrc[j] = p.w + static_cast<size_t>(min(n0 + r, p.N - 1)) * p.K + schunk * 8;
-    }
+    for (int j = 0; j < XU; ++j) xrow[j] = min(m0 + j * ROWS_PER_PASS + srow, p.M - 1);
+#pragma unroll
+    for (int j = 0; j < WU; ++j)
+        wsrc[j] = p.w + static_cast<size_t>(min(n0 + j * ROWS_PER_PASS + srow, p.N - 1)) * p.K + schunk * 8;
 
     auto stage = [&](int buf, int k0) {
-        char* xs = smem + buf * (2 * TILE_BYTES);
-        char* ws = xs + TILE_BYTES;
+        char* xs = smem + buf * STAGE_BYTES;
+        char* ws = xs + XT_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int unit0 = j * 256 + wave * 64;            // wave-uniform LDS destination
+        for (int j = 0; j < XU; ++j) {
             const half_t* xsrc = x_row_ptr<SPATIAL>(p, xrow[j], k0) + schunk * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)xsrc, (lptr_t)(xs + unit0 * 16), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(ws + unit0 * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)xsrc, (lptr_t)(xs + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < WU; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(ws + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
         }
     };
 
@@ -147,56 +164,56 @@ conv_gemm_kernel(const ConvGemmParams p)
     const int fsw = (frow >> 1) & 7;
     int foff[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        foff[s] = frow * 128 + (((s * 2 + hi) ^ fsw) << 4);
-    }
+    for (int s = 0; s < 4; ++s) foff[s] = frow * 128 + (((s * 2 + hi) ^ fsw) << 4);
 
-    float16v acc[2][2];
+    float16v acc[NT][MT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const bool wave_active = (n0 + wn * 64) < p.N;   // N is a multiple of 64
+    const bool wave_active = (n0 + wn * (NT * 32)) < p.N;   // N is a multiple of NT*32 per wave
     const int nk = p.K / BK;
 
     stage(0, 0);
+    const float4* tab = nullptr;
+    if constexpr (ACT == ACT_WSILU) {
+        // WSiLU coefficient table -> LDS (behind the two stages); visible after the first barrier
+        float4* t = reinterpret_cast<float4*>(smem + 2 * STAGE_BYTES);
+        for (int i = tid; i < WSILU_SEGMENTS; i += NTHREADS) t[i] = p.wsilu[i];
+        tab = t;
+    }
     for (int t = 0; t < nk; ++t) {
         __syncthreads();                 // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
-        if (t + 1 < nk) {
-            stage((t + 1) & 1, (t + 1) * BK);
-        }
-        const char* xs = smem + (t & 1) * (2 * TILE_BYTES) + wm * (64 * 128);
-        const char* ws = smem + (t & 1) * (2 * TILE_BYTES) + TILE_BYTES + wn * (64 * 128);
+        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+        const char* xs = smem + (t & 1) * STAGE_BYTES + wm * (MT * 32 * 128);
+        const char* ws = smem + (t & 1) * STAGE_BYTES + XT_BYTES + wn * (NT * 32 * 128);
         if (wave_active) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                half8 xf[2], wf[2];
+                half8 xf[MT], wf[NT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    xf[i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s]);
-                    wf[i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s]);
-                }
+                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s]);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s]);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
             }
         }
     }
-    if (!wave_active) {
-        return;
-    }
+    if (!wave_active) return;
 
-    // ---- epilogue. acc[nt][mt][r]: pixel m = m0 + wm*64 + mt*32 + (lane&31),
-    //      channel n = n0 + wn*64 + nt*32 + 8*(r>>2) + 4*hi + (r&3)
-    const int nbase = n0 + wn * 64;
+    // ---- epilogue. acc[nt][mt][r]: pixel m = m0 + (wm*MT + mt)*32 + (lane&31),
+    //      channel n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
+    const int nbase = n0 + wn * (NT * 32);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + wm * 64 + mt * 32 + (lane & 31);
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (wm * MT + mt) * 32 + (lane & 31);
         const bool m_ok = m < p.M;
         size_t orow;                                  // output pixel index
         if constexpr (UPSAMPLE) {
@@ -206,38 +223,42 @@ conv_gemm_kernel(const ConvGemmParams p)
             orow = static_cast<size_t>(m);
         }
         if constexpr (CHUNK) {
-            // z = wsilu(acc + bias) ; s = ((z0 + z1) + z2) + z3 over 4 adjacent channels
-            float s[2][4];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int np = 0; np < NT / 2; ++np) {
+                // z = wsilu(acc + bias) ; s = ((z0 + z1) + z2) + z3 over 4 adjacent channels
+                float s[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nt = 2 * np + h;
+                        const int n = nbase + nt * 32 + 8 * g + 4 * hi;
+                        const half4 b4 = *reinterpret_cast<const half4*>(p.bias + n);
+                        float z[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[nt][mt][4 * g + e] + static_cast<float>(b4[e]);
+                            z[e] = (ACT == ACT_WSILU) ? wsilu_spec(v, tab) : v;
+                        }
+                        s[h][g] = ((z[0] + z[1]) + z[2]) + z[3];
+                    }
+                // lower half-wave collects the 8 outputs of tile 2np, upper half-wave those of 2np+1
+                half8 o;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = nbase + nt * 32 + 8 * g + 4 * hi;
-                    const half4 b4 = *reinterpret_cast<const half4*>(p.bias + n);
-                    float z[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[nt][mt][4 * g + e] + static_cast<float>(b4[e]);
-                        z[e] = (ACT == ACT_WSILU) ? wsilu_spec(v) : v;
-                    }
-                    s[nt][g] = ((z[0] + z[1]) + z[2]) + z[3];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[0][g]),
+                                                                     __float_as_uint(s[1][g]), false, false);
+                    o[2 * g] = to_half(__uint_as_float(sw[0]));
+                    o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
                 }
-            // lower half-wave collects the 8 outputs of nt = 0, upper half-wave those of nt = 1
-            half8 o;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[0][g]),
-                                                                 __float_as_uint(s[1][g]), false, false);
-                o[2 * g] = to_half(__uint_as_float(sw[0]));
-                o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
-            }
-            if (m_ok) {
-                const int co = (nbase >> 2) + hi * 8;
-                *reinterpret_cast<half8*>(p.y + orow * p.ldy + co) = o;
+                if (m_ok) {
+                    const int co = ((nbase + np * 64) >> 2) + hi * 8;
+                    *reinterpret_cast<half8*>(p.y + orow * p.ldy + co) = o;
+                }
             }
         } else {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {          // pair of 4-channel groups (2pr, 2pr+1)
                     float v[8];
@@ -258,7 +279,7 @@ conv_gemm_kernel(const ConvGemmParams p)
                     }
                     if constexpr (ACT == ACT_WSILU) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = wsilu_spec(v[e]);
+                        for (int e = 0; e < 8; ++e) v[e] = wsilu_spec(v[e], tab);
                     }
                     if (m_ok) {
                         if constexpr (NRES >= 1) {
@@ -293,11 +314,24 @@ conv_gemm_kernel(const ConvGemmParams p)
     }
 }
 
-// ---- optional per-launch timing (bench.py's roofline leg)
+// ---- WSiLU table in device memory (uploaded once, outside any capture)
+const float4* wsilu_table_device()
+{
+    static float4* dev = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        hip_check(hipMalloc(&dev, WSILU_TABLE_BYTES), "hipMalloc(wsilu table)");
+        hip_check(hipMemcpy(dev, kWsiluTable, WSILU_TABLE_BYTES, hipMemcpyHostToDevice), "upload wsilu table");
+    });
+    return dev;
+}
+
+// ---- optional per-launch timing (bench.py's roofline leg): hipExtLaunchKernel stamps the
+// kernel's own begin / end into the two events
 struct GemmProfile {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    std::vector<double> flops;
+    std::vector<GemmLaunchInfo> info;
     size_t used = 0;
 };
 
@@ -307,40 +341,53 @@ GemmProfile& profile()
     return g;
 }
 
-template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
-void launch(const ConvGemmParams& p, hipStream_t stream)
+template <int WM, int WN, int MT, int NT, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
 {
-    GemmProfile& pf = profile();
-    hipEvent_t ev_stop = nullptr;
-    if (pf.on) {
-        if (pf.used == pf.events.size()) {
-            hipEvent_t a, b;
-            hip_check(hipEventCreate(&a), "hipEventCreate");
-            hip_check(hipEventCreate(&b), "hipEventCreate");
-            pf.events.emplace_back(a, b);
-            pf.flops.push_back(0.0);
-        }
-        pf.flops[pf.used] = 2.0 * p.M * p.N * p.K;
-        hip_check(hipEventRecord(pf.events[pf.used].first, stream), "hipEventRecord");
-        ev_stop = pf.events[pf.used].second;
-        ++pf.used;
-    }
-    struct Stop {
-        hipEvent_t e; hipStream_t s;
-        ~Stop() { if (e) (void)hipEventRecord(e, s); }
-    } stop{ ev_stop, stream };
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHREADS = WM * WN * 64;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    auto kern = conv_gemm_kernel<SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>;
+    auto kern = conv_gemm_kernel<WM, WN, MT, NT, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>;
     static bool attr_set = false;
-    const int smem_bytes = 4 * TILE_BYTES;
+    const int smem_bytes = 2 * (BM + BN) * BK * 2 + (ACT == ACT_WSILU ? WSILU_TABLE_BYTES : 0);
     if (!attr_set) {
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
                   "hipFuncSetAttribute(conv_gemm)");
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), smem_bytes, stream, p);
+    GemmProfile& pf = profile();
+    if (pf.on) {
+        if (pf.used == pf.events.size()) {
+            hipEvent_t a, b;
+            hip_check(hipEventCreate(&a), "hipEventCreate");
+            hip_check(hipEventCreate(&b), "hipEventCreate");
+            pf.events.emplace_back(a, b);
+            pf.info.push_back(GemmLaunchInfo{});
+        }
+        pf.info[pf.used] = GemmLaunchInfo{ p.M, p.N, p.K,
+                                           (SPATIAL ? 1 : 0) | (ACT << 1) | (CHUNK ? 4 : 0) | (NRES << 3) |
+                                               (QUANT ? 32 : 0) | (UPSAMPLE ? 64 : 0) | (BM << 8), 0.f };
+        hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), smem_bytes, stream, pf.events[pf.used].first,
+                              pf.events[pf.used].second, 0, p);
+        ++pf.used;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), smem_bytes, stream, p);
+    }
     hip_check(hipGetLastError(), "conv_gemm launch");
+}
+
+// Tile shape per launch: the 128x128 tile unless the grid would leave most of the 256 CUs
+// (2 resident blocks each) idle, then 64x128.
+template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+void launch(ConvGemmParams p, hipStream_t stream)
+{
+    p.wsilu = (ACT == ACT_WSILU) ? wsilu_table_device() : nullptr;
+    const long long tiles128 = static_cast<long long>((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (tiles128 < 640) {
+        launch_cfg<2, 2, 1, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+    } else {
+        launch_cfg<2, 2, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+    }
 }
 
 void check_common(const ConvGemmParams& p)
@@ -359,6 +406,12 @@ void check_common(const ConvGemmParams& p)
 
 }  // namespace
 
+void kernels_init()
+{
+    (void)wsilu_table_device();
+    symbols_init();
+}
+
 void gemm_profile_enable(bool on)
 {
     profile().on = on;
@@ -369,16 +422,28 @@ void gemm_profile_reset()
     profile().used = 0;
 }
 
+size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap)
+{
+    GemmProfile& pf = profile();
+    for (size_t i = 0; i < pf.used && i < cap; ++i) {
+        float e = 0.f;
+        hip_check(hipEventSynchronize(pf.events[i].second), "hipEventSynchronize");
+        hip_check(hipEventElapsedTime(&e, pf.events[i].first, pf.events[i].second), "hipEventElapsedTime");
+        out[i] = pf.info[i];
+        out[i].ms = e;
+    }
+    return pf.used;
+}
+
 void gemm_profile_collect(double* ms, double* flops, long long* launches)
 {
     GemmProfile& pf = profile();
+    std::vector<GemmLaunchInfo> rec(pf.used);
+    gemm_profile_launches(rec.data(), rec.size());
     double t = 0, f = 0;
-    for (size_t i = 0; i < pf.used; ++i) {
-        hip_check(hipEventSynchronize(pf.events[i].second), "hipEventSynchronize");
-        float e = 0.f;
-        hip_check(hipEventElapsedTime(&e, pf.events[i].first, pf.events[i].second), "hipEventElapsedTime");
-        t += e;
-        f += pf.flops[i];
+    for (const GemmLaunchInfo& r : rec) {
+        t += r.ms;
+        f += 2.0 * r.M * r.N * r.K;
     }
     *ms = t;
     *flops = f;

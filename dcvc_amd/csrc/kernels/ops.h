@@ -20,6 +20,10 @@ inline void hip_check(hipError_t e, const char* what)
     }
 }
 
+// One-time device-side tables (WSiLU coefficients, scale->index LUT). Call once per process
+// before the first launch and outside any graph capture.
+void kernels_init();
+
 // ---------------------------------------------------------------- per-kernel timing (conv_gemm.hip)
 // When enabled, every contraction launch is bracketed by a pair of HIP events on its own stream
 // (launches must then be eager, not captured). collect() synchronises the events and returns
@@ -27,6 +31,11 @@ inline void hip_check(hipError_t e, const char* what)
 void gemm_profile_enable(bool on);
 void gemm_profile_reset();
 void gemm_profile_collect(double* ms, double* flops, long long* launches);
+struct GemmLaunchInfo {
+    int M, N, K, variant;   // variant bits: 1 spatial, 2 wsilu, 4 chunk-add, 8/16 residuals, 32 quant, 64 upsample
+    float ms;
+};
+size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap);
 
 // ---------------------------------------------------------------- dense convolutions (conv_gemm.hip)
 struct Conv1x1Desc {

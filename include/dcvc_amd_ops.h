@@ -85,6 +85,8 @@ int dcvc_y_step_dec_restore(const void* decoded, const void* cond, const void* b
 int dcvc_gemm_profile_enable(int on);
 int dcvc_gemm_profile_reset(void);
 int dcvc_gemm_profile_collect(double* ms, double* flops, long long* launches);
+/* per-launch records {int M, N, K, variant; float ms}; returns the number of launches recorded */
+long long dcvc_gemm_profile_launches(void* records, long long cap);
 
 #ifdef __cplusplus
 }

@@ -45,13 +45,14 @@ def _mark(target, sources):
 def build_liboracle(force=False):
     srcs = [os.path.join(HERE, s) for s in C_SOURCES if os.path.exists(os.path.join(HERE, s))]
     out = os.path.join(HERE, "liboracle.so")
-    if force or _stale(out, srcs):
+    deps = srcs + [os.path.join(HERE, "wsilu_table.h")]
+    if force or _stale(out, deps):
         # -ffp-contract=off: the oracle spells out every fused multiply-add with fmaf(); the
         # compiler must not invent or remove any (bit-exact arithmetic specification).
         cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                "-fno-fast-math", "-Wall", "-Wextra", "-o", out] + srcs + ["-lm"]
         subprocess.check_call(cmd)
-        _mark(out, srcs)
+        _mark(out, deps)
     return out
 
 
