@@ -376,13 +376,27 @@ void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
     hip_check(hipGetLastError(), "conv_gemm launch");
 }
 
-// Tile shape per launch: the 128x128 tile unless the grid would leave most of the 256 CUs
-// (2 resident blocks each) idle, then 64x128.
+// Tile shape per launch. The L2 -> LDS path delivers ~56 B/clk per CU, a 128x128x64 tile needs
+// 64 B/clk to keep the matrix cores busy, a 256x256 one 31 B/clk: the big P8 layers therefore
+// run 256-pixel tiles with 8 waves (256x256 when N allows, else 256x192, both exactly one or
+// three rounds of the 256 CUs at 1080p), small grids fall back to 128x128 / 64x128 so that the
+// chip is still filled.
 template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
 void launch(ConvGemmParams p, hipStream_t stream)
 {
     p.wsilu = (ACT == ACT_WSILU) ? wsilu_table_device() : nullptr;
     const long long tiles128 = static_cast<long long>((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const long long mt256 = (p.M + 255) / 256;
+    if (p.N % 256 == 0 && mt256 * (p.N / 256) >= 224) {
+        launch_cfg<4, 2, 2, 4, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+        return;
+    }
+    if constexpr (!CHUNK) {
+        if (p.N % 192 == 0 && mt256 * (p.N / 192) >= 224) {
+            launch_cfg<4, 2, 2, 3, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+            return;
+        }
+    }
     if (tiles128 < 640) {
         launch_cfg<2, 2, 1, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
     } else {

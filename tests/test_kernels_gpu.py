@@ -50,6 +50,11 @@ CONV_CASES = [
     dict(P=2048, K=384, N=1536, wsilu=True, chunk=True, name="bias_wsilu_chunk_add_384"),
     dict(P=129, K=512, N=192, q2=True, name="bias_then_scale_n192"),
     dict(P=4096, K=2048, N=512, name="bias_k2048"),
+    # 1080p-sized grids: the 256-pixel tile shapes (256x256 and 256x192), ragged last tile
+    dict(P=32641, K=384, N=1536, wsilu=True, chunk=True, name="p8_chunk_add_256x256"),
+    dict(P=32600, K=384, N=384, r1=True, name="p8_shortcut_256x192"),
+    dict(P=32640, K=192, N=768, wsilu=True, name="p8_wsilu_256x256"),
+    dict(P=30000, K=384, N=384, r1=True, r2=True, q2=True, name="p8_shortcut2_scale_256x192"),
 ]
 
 
@@ -94,7 +99,7 @@ def test_conv1x1(ops, case):
     # bit-exact against the oracle (measured matrix-core arithmetic, oracle/nn_oracle.c)
     from oracle import nn
     np_ = lambda t: None if t is None else t.cpu().numpy()
-    rows = slice(0, min(P, 640))
+    rows = slice(max(0, P - 400), P) if P > 20000 else slice(0, min(P, 640))
     orc = nn.conv1x1(np_(x)[rows], np_(w), np_(b), r1=None if r1 is None else np_(r1)[rows],
                      r2=None if r2 is None else np_(r2)[rows], q=np_(q), q2=np_(q2),
                      wsilu=bool(case.get("wsilu")), chunk_add=bool(case.get("chunk")))
