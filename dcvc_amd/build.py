@@ -26,6 +26,8 @@ COMMON = [
     # arithmetic policy: no fast-math, no implicit contraction - every fma is spelled fmaf()
     # so that the CPU oracle can reproduce the device arithmetic bit for bit.
     "-ffp-contract=off", "-fno-fast-math",
+    # SLP packing of scalar fp32 math into v_pk_* costs more v_mov / s_nop than it saves on gfx950
+    "-fno-slp-vectorize",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ]
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-munsafe-fp-atomics"]

@@ -31,13 +31,47 @@ __device__ __forceinline__ float wsilu_spec(float v, const float4* tab)
 {
     float t = fmaf(v, 16.0f, 128.0f);
     t = fminf(fmaxf(t, 0.0f), 255.99998f);
-    const float fl = floorf(t);
-    const float f = t - fl;
-    const float4 c = tab[static_cast<int>(fl)];
+    const float f = __builtin_amdgcn_fractf(t);      // t - floor(t), exact
+    const float4 c = tab[static_cast<int>(t)];        // t >= 0: truncation == floor
     float p = fmaf(c.w, f, c.z);
     p = fmaf(p, f, c.y);
     p = fmaf(p, f, c.x);
     return v * p;
+}
+
+// Batched forms: all table indices first, then all LDS reads, then the polynomials - the loads
+// overlap instead of exposing one LDS round trip per element.
+__device__ __forceinline__ void wsilu8(float (&v)[8], const float4* tab)
+{
+    float f[8];
+    float4 c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = fmaf(v[e], 16.0f, 128.0f);
+        t = fminf(fmaxf(t, 0.0f), 255.99998f);
+        f[e] = __builtin_amdgcn_fractf(t);
+        c[e] = tab[static_cast<int>(t)];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float p = fmaf(c[e].w, f[e], c[e].z);
+        p = fmaf(p, f[e], c[e].y);
+        p = fmaf(p, f[e], c[e].x);
+        v[e] = v[e] * p;
+    }
+}
+
+__device__ __forceinline__ void wsilu16(const float16v& a, float (&z)[16], const float4* tab)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = a[8 * h + e];
+        wsilu8(v, tab);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[8 * h + e] = v[e];
+    }
 }
 
 // C round(): half away from zero (the reference's symbol kernels call round() on a float,

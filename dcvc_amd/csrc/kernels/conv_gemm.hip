@@ -38,6 +38,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -96,7 +97,7 @@ __device__ __forceinline__ const half_t* x_row_ptr(const ConvGemmParams& p, int 
     }
 }
 
-template <int WM, int WN, int MT, int NT, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+template <int WM, int WN, int MT, int NT, int STAGES, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_gemm_kernel(const ConvGemmParams p)
 {
@@ -111,6 +112,11 @@ conv_gemm_kernel(const ConvGemmParams p)
     constexpr int ROWS_PER_PASS = NTHREADS / 8;
     static_assert(ROWS_PER_PASS % 16 == 0, "swizzle term must not depend on the pass");
     static_assert(!CHUNK || NT % 2 == 0, "chunk-add pairs two channel tiles");
+    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
+    constexpr int BNO = CHUNK ? BN / 4 : BN;             // channels per output row of the tile
+    constexpr int OCH = BNO / 8;                         // 16-B chunks per output row
+    constexpr int OUNITS = BM * OCH / NTHREADS;          // output chunks per thread
+    static_assert(BM * OCH % NTHREADS == 0 && BM * BNO * 2 <= STAGES * STAGE_BYTES, "output tile must fit");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (X tile, W tile) [+ table]
 
@@ -166,30 +172,78 @@ conv_gemm_kernel(const ConvGemmParams p)
 #pragma unroll
     for (int s = 0; s < 4; ++s) foff[s] = frow * 128 + (((s * 2 + hi) ^ fsw) << 4);
 
-    float16v acc[NT][MT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
     const bool wave_active = (n0 + wn * (NT * 32)) < p.N;   // N is a multiple of NT*32 per wave
     const int nk = p.K / BK;
 
+    // The accumulators start at the bias (arithmetic policy: y = ((bias + p_0) + p_1) + ...), so
+    // the epilogue has no bias traffic at all. acc[nt][mt][r] belongs to channel
+    // n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3).
+    float16v acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        float16v init;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) init[r] = 0.f;
+        if (p.bias != nullptr && wave_active) {
+            const half_t* bp = p.bias + n0 + (wn * NT + a) * 32 + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) init[4 * g + e] = static_cast<float>(b4[e]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = init;
+    }
+
+    // first residual: whole rows, 16 B per lane, consumed after the main loop
+    half8 rpre[NRES >= 1 ? OUNITS : 1];
+    if constexpr (NRES >= 1) {
+#pragma unroll
+        for (int j = 0; j < OUNITS; ++j) {
+            const int u = j * NTHREADS + tid;
+            const int row = min(m0 + u / OCH, p.M - 1);
+            const int ch = min(n0 + (u % OCH) * 8, p.N - 8);
+            rpre[j] = *reinterpret_cast<const half8*>(p.r1 + static_cast<size_t>(row) * p.ldr1 + ch);
+        }
+    }
+
     stage(0, 0);
+    if constexpr (STAGES == 3) {
+        if (nk > 1) stage(1, BK);
+    }
     const float4* tab = nullptr;
     if constexpr (ACT == ACT_WSILU) {
-        // WSiLU coefficient table -> LDS (behind the two stages); visible after the first barrier
-        float4* t = reinterpret_cast<float4*>(smem + 2 * STAGE_BYTES);
+        // WSiLU coefficient table -> LDS (behind the stages); visible after the first barrier
+        float4* t = reinterpret_cast<float4*>(smem + STAGES * STAGE_BYTES);
         for (int i = tid; i < WSILU_SEGMENTS; i += NTHREADS) t[i] = p.wsilu[i];
         tab = t;
     }
     for (int t = 0; t < nk; ++t) {
-        __syncthreads();                 // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
-        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
-        const char* xs = smem + (t & 1) * STAGE_BYTES + wm * (MT * 32 * 128);
-        const char* ws = smem + (t & 1) * STAGE_BYTES + XT_BYTES + wn * (NT * 32 * 128);
+        int cur;
+        if constexpr (STAGES == 2) {
+            __syncthreads();             // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
+            if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+            cur = t & 1;
+        } else {
+            // Two tiles in flight: wait only for the OLDER one (counted vmcnt), keep the younger
+            // across the barrier. __syncthreads() would drain the LDS-DMA queue, hence the raw
+            // barrier. After the barrier every wave has finished computing tile t-1, so its
+            // buffer ((t+2) % 3) may be refilled.
+            if (t + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XU + WU) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = t % 3;
+            if (t + 2 < nk) stage((t + 2) % 3, (t + 2) * BK);
+        }
+        const char* xs = smem + cur * STAGE_BYTES + wm * (MT * 32 * 128);
+        const char* ws = smem + cur * STAGE_BYTES + XT_BYTES + wn * (NT * 32 * 128);
         if (wave_active) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -206,91 +260,88 @@ conv_gemm_kernel(const ConvGemmParams p)
             }
         }
     }
-    if (!wave_active) return;
-
     // ---- epilogue. acc[nt][mt][r]: pixel m = m0 + (wm*MT + mt)*32 + (lane&31),
     //      channel n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
-    const int nbase = n0 + wn * (NT * 32);
+    // The block's output tile goes through LDS (the stage buffers are dead now) so that global
+    // memory sees whole 128-B lines: per-lane stores at a pixel stride touch a different line per
+    // lane and were 2/3 of the kernel time. The first residual arrives the same way (prefetched
+    // row-wise into registers at kernel start, parked in the LDS tile here).
+    __syncthreads();                                   // every wave is done with the stage buffers
+    char* otile = smem;
+    constexpr int SWZ = OCH >= 8 ? 7 : OCH - 1;        // rows narrower than 128 B swizzle inside the row
+    auto oaddr = [&](int row, int cidx) {              // 16-B chunk cidx of tile row `row`, bank swizzled
+        return otile + row * (BNO * 2) + (((cidx & ~SWZ) | ((cidx & SWZ) ^ (row & SWZ))) << 4);
+    };
+    if constexpr (NRES >= 1) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + (wm * MT + mt) * 32 + (lane & 31);
-        const bool m_ok = m < p.M;
-        size_t orow;                                  // output pixel index
-        if constexpr (UPSAMPLE) {
-            const int yy = m / p.in_w, xx = m - yy * p.in_w;
-            orow = static_cast<size_t>(2 * yy + p.up_dy) * (2 * p.in_w) + (2 * xx + p.up_dx);
-        } else {
-            orow = static_cast<size_t>(m);
+        for (int j = 0; j < OUNITS; ++j) {
+            const int u = j * NTHREADS + tid;
+            *reinterpret_cast<half8*>(oaddr(u / OCH, u % OCH)) = rpre[j];
         }
-        if constexpr (CHUNK) {
+        __syncthreads();
+    }
+    if (wave_active) {
+        const int ntile = wn * (NT * 32);              // channel offset of this wave inside the tile
 #pragma unroll
-            for (int np = 0; np < NT / 2; ++np) {
-                // z = wsilu(acc + bias) ; s = ((z0 + z1) + z2) + z3 over 4 adjacent channels
-                float s[2][4];
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = (wm * MT + mt) * 32 + (lane & 31);
+            const int m = m0 + row;
+            if constexpr (CHUNK) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int np = 0; np < NT / 2; ++np) {
+                    // z = wsilu(acc) ; s = ((z0 + z1) + z2) + z3 over 4 adjacent channels
+                    float s[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int nt = 2 * np + h;
+                        float z[16];
+                        if constexpr (ACT == ACT_WSILU) {
+                            wsilu16(acc[nt][mt], z, tab);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) z[e] = acc[nt][mt][e];
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) s[h][g] = ((z[4 * g] + z[4 * g + 1]) + z[4 * g + 2]) + z[4 * g + 3];
+                    }
+                    // lower half-wave collects the 8 outputs of tile 2np, upper half-wave those of 2np+1
+                    half8 o;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int nt = 2 * np + h;
-                        const int n = nbase + nt * 32 + 8 * g + 4 * hi;
-                        const half4 b4 = *reinterpret_cast<const half4*>(p.bias + n);
-                        float z[4];
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[0][g]),
+                                                                         __float_as_uint(s[1][g]), false, false);
+                        o[2 * g] = to_half(__uint_as_float(sw[0]));
+                        o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
+                    }
+                    *reinterpret_cast<half8*>(oaddr(row, ((ntile + np * 64) >> 5) + hi)) = o;
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {          // pair of 4-channel groups (2pr, 2pr+1)
+                        float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float v = acc[nt][mt][4 * g + e] + static_cast<float>(b4[e]);
-                            z[e] = (ACT == ACT_WSILU) ? wsilu_spec(v, tab) : v;
+                            const auto sw = __builtin_amdgcn_permlane32_swap(
+                                __float_as_uint(acc[nt][mt][8 * pr + e]),
+                                __float_as_uint(acc[nt][mt][8 * pr + 4 + e]), false, false);
+                            v[e] = __uint_as_float(sw[0]);
+                            v[4 + e] = __uint_as_float(sw[1]);
                         }
-                        s[h][g] = ((z[0] + z[1]) + z[2]) + z[3];
-                    }
-                // lower half-wave collects the 8 outputs of tile 2np, upper half-wave those of 2np+1
-                half8 o;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[0][g]),
-                                                                     __float_as_uint(s[1][g]), false, false);
-                    o[2 * g] = to_half(__uint_as_float(sw[0]));
-                    o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
-                }
-                if (m_ok) {
-                    const int co = ((nbase + np * 64) >> 2) + hi * 8;
-                    *reinterpret_cast<half8*>(p.y + orow * p.ldy + co) = o;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {          // pair of 4-channel groups (2pr, 2pr+1)
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(
-                            __float_as_uint(acc[nt][mt][8 * pr + e]),
-                            __float_as_uint(acc[nt][mt][8 * pr + 4 + e]), false, false);
-                        v[e] = __uint_as_float(sw[0]);
-                        v[4 + e] = __uint_as_float(sw[1]);
-                    }
-                    // this lane now holds channels cb .. cb+7 of pixel m
-                    const int cb = nbase + nt * 32 + 16 * pr + 8 * hi;
-                    if (p.bias != nullptr) {
-                        const half8 b8 = *reinterpret_cast<const half8*>(p.bias + cb);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(b8[e]);
-                    }
-                    if constexpr (ACT == ACT_WSILU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = wsilu_spec(v[e], tab);
-                    }
-                    if (m_ok) {
+                        // this lane now holds channels cb .. cb+7 of pixel m
+                        const int ct = ntile + nt * 32 + 16 * pr + 8 * hi;     // inside the tile
+                        const int cb = n0 + ct;
+                        if constexpr (ACT == ACT_WSILU) wsilu8(v, tab);
+                        half8* slot = reinterpret_cast<half8*>(oaddr(row, ct >> 3));
                         if constexpr (NRES >= 1) {
-                            const half8 r8 = *reinterpret_cast<const half8*>(
-                                p.r1 + static_cast<size_t>(m) * p.ldr1 + cb);
+                            const half8 r8 = *slot;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
                         }
                         if constexpr (NRES >= 2) {
                             const half8 r8 = *reinterpret_cast<const half8*>(
-                                p.r2 + static_cast<size_t>(m) * p.ldr2 + cb);
+                                p.r2 + static_cast<size_t>(min(m, p.M - 1)) * p.ldr2 + cb);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
                         }
@@ -307,9 +358,30 @@ conv_gemm_kernel(const ConvGemmParams p)
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
                         }
-                        *reinterpret_cast<half8*>(p.y + orow * p.ldy + cb) = o;
+                        *slot = o;
                     }
-                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- whole-line stores: consecutive lanes write consecutive 16-B chunks of one pixel row
+    const int n0o = CHUNK ? (n0 >> 2) : n0;
+    const int nout = CHUNK ? (p.N >> 2) : p.N;
+#pragma unroll
+    for (int j = 0; j < OUNITS; ++j) {
+        const int u = j * NTHREADS + tid;
+        const int row = u / OCH, ch = u % OCH;
+        const int m = m0 + row;
+        if (m < p.M && n0o + ch * 8 < nout) {
+            size_t orow;
+            if constexpr (UPSAMPLE) {
+                const int yy = m / p.in_w, xx = m - yy * p.in_w;
+                orow = static_cast<size_t>(2 * yy + p.up_dy) * (2 * p.in_w) + (2 * xx + p.up_dx);
+            } else {
+                orow = static_cast<size_t>(m);
+            }
+            *reinterpret_cast<half8*>(p.y + orow * p.ldy + n0o + ch * 8) =
+                *reinterpret_cast<const half8*>(oaddr(row, ch));
         }
     }
 }
@@ -341,14 +413,14 @@ GemmProfile& profile()
     return g;
 }
 
-template <int WM, int WN, int MT, int NT, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+template <int WM, int WN, int MT, int NT, int STAGES, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
 void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
 {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHREADS = WM * WN * 64;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    auto kern = conv_gemm_kernel<WM, WN, MT, NT, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>;
+    auto kern = conv_gemm_kernel<WM, WN, MT, NT, STAGES, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>;
     static bool attr_set = false;
-    const int smem_bytes = 2 * (BM + BN) * BK * 2 + (ACT == ACT_WSILU ? WSILU_TABLE_BYTES : 0);
+    const int smem_bytes = STAGES * (BM + BN) * BK * 2 + (ACT == ACT_WSILU ? WSILU_TABLE_BYTES : 0);
     if (!attr_set) {
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
@@ -366,7 +438,7 @@ void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
         }
         pf.info[pf.used] = GemmLaunchInfo{ p.M, p.N, p.K,
                                            (SPATIAL ? 1 : 0) | (ACT << 1) | (CHUNK ? 4 : 0) | (NRES << 3) |
-                                               (QUANT ? 32 : 0) | (UPSAMPLE ? 64 : 0) | (BM << 8), 0.f };
+                                               (QUANT ? 32 : 0) | (UPSAMPLE ? 64 : 0) | (BM << 8) | (BN << 18) | (STAGES << 28), 0.f };
         hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), smem_bytes, stream, pf.events[pf.used].first,
                               pf.events[pf.used].second, 0, p);
         ++pf.used;
@@ -387,20 +459,33 @@ void launch(ConvGemmParams p, hipStream_t stream)
     p.wsilu = (ACT == ACT_WSILU) ? wsilu_table_device() : nullptr;
     const long long tiles128 = static_cast<long long>((p.M + 127) / 128) * ((p.N + 127) / 128);
     const long long mt256 = (p.M + 255) / 256;
+    static const int force = [] { const char* e = getenv("DCVC_GEMM_CFG"); return e ? atoi(e) : 0; }();
+    if (force) {      // tuning experiments only
+        switch (force) {
+        case 1: launch_cfg<2, 2, 2, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 2: launch_cfg<2, 2, 2, 2, 3, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 3: launch_cfg<4, 2, 2, 2, 3, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 4: launch_cfg<4, 2, 2, 4, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 5: launch_cfg<2, 2, 1, 2, 3, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 6: launch_cfg<2, 2, 1, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 7: launch_cfg<4, 2, 2, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        default: break;
+        }
+    }
     if (p.N % 256 == 0 && mt256 * (p.N / 256) >= 224) {
-        launch_cfg<4, 2, 2, 4, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+        launch_cfg<4, 2, 2, 4, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
         return;
     }
     if constexpr (!CHUNK) {
         if (p.N % 192 == 0 && mt256 * (p.N / 192) >= 224) {
-            launch_cfg<4, 2, 2, 3, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+            launch_cfg<4, 2, 2, 3, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
             return;
         }
     }
     if (tiles128 < 640) {
-        launch_cfg<2, 2, 1, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+        launch_cfg<2, 2, 1, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
     } else {
-        launch_cfg<2, 2, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+        launch_cfg<2, 2, 2, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
     }
 }
 

@@ -7,7 +7,7 @@
  *   conv1x1 family  /root/reference/src/layers/extensions/inference/cutlass/conv1x1_bias*.cu
  *                   (the sm<75 ATen fallbacks state the math, e.g.
  *                    conv1x1_bias_wsilu_chunk_add.cu:364-377), epilogue order of
- *                   cutlass/cutlass_epilogue.h:79-104: acc + bias -> WSiLU -> + residuals -> * quant
+ *                   cutlass/cutlass_epilogue.h:79-104: (bias + acc) -> WSiLU -> + residuals -> * quant
  *   depthwise 3x3   cutlass/d3x3.cu:443-446 (no bias, zero padding)
  *   WSiLU           src/layers/layers.py:106-111  x * sigmoid(4x)
  *
@@ -273,14 +273,12 @@ void orc_conv1x1(const uint16_t* x, int ldx, const uint16_t* w, const uint16_t* 
         }
         for (n = 0; n < N; n++) {
             const hparts* wr = ws + (size_t)n * K;
-            float acc = 0.0f;
+            /* the accumulator starts at the bias (dcvc_amd/csrc/kernels/conv_gemm.hip) */
+            float acc = bias ? half_to_float(bias[n]) : 0.0f;
             for (k = 0; k < K; k += 16) {
                 /* the product is W[n][k] * X[p][k]: operand order does not matter for the value */
                 acc = mfma_group(acc, wr + k, xs + k);
                 acc = mfma_group(acc, wr + k + 8, xs + k + 8);
-            }
-            if (bias) {
-                acc = acc + half_to_float(bias[n]);
             }
             if (flags & ORC_WSILU) {
                 acc = wsilu_spec(acc);
