@@ -245,21 +245,32 @@ conv_gemm_kernel(const ConvGemmParams p)
         const char* xs = smem + cur * STAGE_BYTES + wm * (MT * 32 * 128);
         const char* ws = smem + cur * STAGE_BYTES + XT_BYTES + wn * (NT * 32 * 128);
         if (wave_active) {
+            // fragments of k-slice s+1 are fetched while the MFMAs of slice s run (register
+            // double buffering; hipcc otherwise waits for all six reads in front of every slice)
+            half8 xf[2][MT], wf[2][NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[0][i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[0]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) wf[0][i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[0]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                half8 xf[MT], wf[NT];
+                if (s < 3) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s]);
+                    for (int i = 0; i < MT; ++i)
+                        xf[(s + 1) & 1][i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s + 1]);
 #pragma unroll
-                for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s]);
+                    for (int i = 0; i < NT; ++i)
+                        wf[(s + 1) & 1][i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s + 1]);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], xf[s & 1][mt], acc[nt][mt], 0, 0, 0);
             }
         }
     }
+
     // ---- epilogue. acc[nt][mt][r]: pixel m = m0 + (wm*MT + mt)*32 + (lane&31),
     //      channel n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
     // The block's output tile goes through LDS (the stage buffers are dead now) so that global

@@ -2,10 +2,12 @@
 # One gpurun session: tests, smoke, bench, rocprof kernel trace. Outputs under gpurun_out/.
 set -x
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/test_gpu.log
 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
 python bench.py --steps 30 --warmup 8 > gpurun_out/bench.log 2>&1
-tail -3 gpurun_out/bench.log
+tail -1 gpurun_out/bench.log
+rm -rf gpurun_out/prof
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py --steps 10 --warmup 4 --no-cpu-baseline > gpurun_out/bench_prof.log 2>&1
-ls -R gpurun_out/prof | head -20
+python tools/rocpd_stats.py gpurun_out/prof/bench_results.db gpurun_out/kernel_stats.csv > /dev/null
+head -12 gpurun_out/kernel_stats.csv | cut -c1-160
