@@ -106,3 +106,49 @@ def param_count(spec):
             k *= d
         n += k
     return n
+
+
+# ---------------------------------------------------------------------------------------- DMC LD
+# /root/reference/src/models/video_model_ld.py:16-21
+LD_FRAME_DELAY = 1
+LD_CH_SRC, LD_CH_Y, LD_CH_Z, LD_CH_D, LD_CH_M = 192, 128, 128, 256, 256
+
+
+def dmc_ld_spec():
+    """Low-delay inter model (video_model_ld.py:24-230), every DepthConvBlock is dcb2."""
+    s = OrderedDict()
+    bit_estimator(s, "bit_estimator_z.", LD_CH_Z)
+    y, z, d, m = LD_CH_Y, LD_CH_Z, LD_CH_D, LD_CH_M
+
+    def chain(prefix, cin, c, n):
+        depth_conv_block(s, prefix + "0.", cin, c, dcb2=True)
+        for i in range(1, n):
+            depth_conv_block(s, prefix + "%d." % i, c, c, dcb2=True)
+
+    chain("feature_adaptor_i.conv.", LD_CH_SRC, m, 4)           # :63-77
+    chain("feature_adaptor_m.conv.", m + d, m, 4)               # :80-92
+    chain("feature_extractor.conv.", m, m, 5)                   # :95-110
+    chain("encoder.conv1.", LD_CH_SRC + m, d, 2)                # :43-60
+    depth_conv_block(s, "encoder.conv2.", d, d, dcb2=True)
+    _conv(s, "encoder.down", d, y, k=3)
+    depth_conv_block(s, "hyper_encoder.conv.0.", y, z, dcb2=True)            # :128-139
+    residual_block_stride2(s, "hyper_encoder.conv.1.", z, z, dcb2=True)
+    residual_block_stride2(s, "hyper_encoder.conv.2.", z, z, dcb2=True)
+    residual_block_upsample(s, "hyper_decoder.conv.0.", z, z, dcb2=True)     # :113-125
+    residual_block_upsample(s, "hyper_decoder.conv.1.", z, z, dcb2=True)
+    depth_conv_block(s, "hyper_decoder.conv.2.", z, y, dcb2=True)
+    residual_block_stride2(s, "temporal_prior_encoder.conv.", m, 2 * y, dcb2=True)   # :187-194
+    chain("y_prior_fusion.conv.", 3 * y, 3 * y, 3)                           # :142-154
+    _conv(s, "y_prior_fusion.conv.3", 3 * y, 3 * y)
+    depth_conv_block(s, "y_spatial_prior.conv.0.", 4 * y, 2 * y, dcb2=True)  # :174-184
+    depth_conv_block(s, "y_spatial_prior.conv.1.", 2 * y, 2 * y, dcb2=True)
+    _conv(s, "y_spatial_prior.conv.2", 2 * y, y)
+    _conv(s, "decoder.up.conv.0", y, 4 * d, bias=False)                      # :24-40
+    chain("decoder.conv1.", d + m, d, 3)
+    _conv(s, "decoder.conv2", d, d)
+    chain("recon_head.conv.", d, d, 3)                                       # :157-171
+    _conv(s, "recon_head.head", d, LD_CH_SRC)
+    s["q_encoder"] = (QP_NUM, d)                                             # :216-218
+    s["q_decoder"] = (QP_NUM, d)
+    s["q_feature"] = (QP_NUM, 2 * y)
+    return s

@@ -190,3 +190,28 @@ class DMCI(CompressionModel):
         x_hat = self._ensure_proxy().decompress(
             np.frombuffer(bit_stream, dtype=np.uint8), qp, sps["height"], sps["width"], ec_part)
         return {"x_hat": x_hat}
+
+
+class DMC(CompressionModel):
+    """video_model_ld.py:191-308 (inference subset): the low-delay inter model. The temporal
+    state (reference feature, memory, context) lives inside the native proxy."""
+    _SPEC = staticmethod(arch.dmc_ld_spec)
+    _PROXY = "DMCLDProxy"
+
+    def clear_dpb(self):
+        """video_model_ld.py:226-229; the native state is overwritten by the next
+        add_ref_feature_from_frame, so there is nothing to release."""
+
+    def add_ref_feature_from_frame(self, frame, apply_feature_adaptor=True):
+        return self._ensure_proxy().add_ref_feature_from_frame(frame, apply_feature_adaptor)
+
+    def compress(self, x, qp, reset_feature_memory, padding_b, padding_r):
+        bit_stream, ec_parallel = self._ensure_proxy().compress(
+            x, qp, bool(reset_feature_memory), padding_b, padding_r)
+        return {"bit_stream": bit_stream.tobytes(), "ec_parallel": ec_parallel}
+
+    def decompress(self, bit_stream, sps, qp, ec_part, reset_feature_memory):
+        x_hat = self._ensure_proxy().decompress(
+            np.frombuffer(bit_stream, dtype=np.uint8), qp, sps["height"], sps["width"], ec_part,
+            bool(reset_feature_memory))
+        return {"x_hat": x_hat}

@@ -24,9 +24,28 @@ _GAIN_OVERRIDES = (
 )
 
 
+# the same for the inter models (spec contains q_encoder): additionally keeps the temporal recurrence
+# memory -> ctx -> feature -> memory contractive so that long sequences stay inside fp16
+_GAIN_OVERRIDES_INTER = (
+    ("feature_adaptor_i.conv.0.adaptor.weight", 2.0),
+    ("feature_adaptor_m.conv.0.adaptor.weight", 0.65),
+    ("feature_extractor.conv.4.ffn.2.weight", 0.5),
+    ("encoder.down.weight", 2.5),
+    ("hyper_encoder.conv.0.adaptor.weight", 0.3),
+    ("hyper_decoder.conv.2.adaptor.weight", 0.15),
+    ("y_prior_fusion.conv.3.weight", 0.35),
+    ("y_spatial_prior.conv.2.weight", 0.35),
+    ("decoder.up.conv.0.weight", 0.3),
+    ("decoder.conv2.weight", 0.35),
+    ("recon_head.head.weight", 0.2),
+)
+
+
 def synthetic_state_dict(spec, seed=0, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     sd = {}
+    inter = "q_encoder" in spec
+    overrides = _GAIN_OVERRIDES_INTER if inter else _GAIN_OVERRIDES
     for name, shape in spec.items():
         if name.startswith("bit_estimator_z."):
             # spread wide enough that table lengths vary across channels (entropy_models.py:113-149)
@@ -39,6 +58,11 @@ def synthetic_state_dict(spec, seed=0, dtype=torch.float32):
                 t = base * torch.exp((qp - 32.0) / 48.0)       # finer quantisation at high qp
             else:
                 t = base * torch.exp(-(qp - 32.0) / 48.0)
+        elif name in ("q_encoder", "q_decoder", "q_feature"):          # inter models
+            qp = torch.arange(shape[0], dtype=torch.float32)[:, None]
+            base = 1.0 + 0.25 * torch.rand(shape, generator=g)
+            sign = {"q_encoder": 1.0, "q_decoder": -1.0, "q_feature": 0.5}[name]
+            t = base * torch.exp(sign * (qp - 32.0) / 48.0)
         elif name.endswith(".weight"):
             cout, cin_g, kh, kw = shape
             fan_in = cin_g * kh * kw
@@ -49,10 +73,17 @@ def synthetic_state_dict(spec, seed=0, dtype=torch.float32):
                 gain = 0.7
             elif ".dc.2." in name:
                 gain = 1.2
-            for key, extra in _GAIN_OVERRIDES:
+            for key, extra in overrides:
                 if name.endswith(key):
                     gain *= extra
             t = torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
+        elif inter and name == "y_prior_fusion.conv.3.bias":
+            # (q_dec | scales | means): quantisation steps around 1, scales that straddle the skip
+            # threshold, small means
+            n = shape[0] // 3
+            t = torch.cat([0.9 + 0.5 * torch.rand(n, generator=g),
+                           0.1 + 0.6 * torch.rand(n, generator=g),
+                           0.05 * torch.randn(n, generator=g)])
         elif name.endswith(".bias"):
             t = torch.randn(shape, generator=g) * 0.02
         else:

@@ -88,17 +88,17 @@ class Net:
         return nn.conv1x1(t, sd[p + "ffn.2.weight"], sd[p + "ffn.2.bias"], r1=sc_ffn,
                           r2=sc if shortcut else None, q=q, q2=q2)
 
-    def rb_stride2(self, x, p):
-        """pixel_unshuffle(2) + 1x1 (== the folded 2x2 stride-2 conv) + DCB(shortcut)."""
+    def rb_stride2(self, x, p, shortcut=True):
+        """pixel_unshuffle(2) + 1x1 (== the folded 2x2 stride-2 conv) + DCB."""
         w = self.sd[p + "down.weight"]                      # [C', 4C, 1, 1], ch = c*4 + dy*2 + dx
         cout, c4 = w.shape[0], w.shape[1]
         w2 = w.reshape(cout, c4 // 4, 2, 2)                 # PyTorch conv layout [C', C, ky, kx]
         out = nn.conv_kxk(x, w2, self.sd[p + "down.bias"], 2, 2, 0)
-        return self.dcb(out, p + "conv.", shortcut=True)
+        return self.dcb(out, p + "conv.", shortcut=shortcut)
 
-    def rb_upsample(self, x, p):
+    def rb_upsample(self, x, p, shortcut=True):
         out = nn.subpel_conv1x1(x, self.sd[p + "up.conv.0.weight"])
-        return self.dcb(out, p + "conv.", shortcut=True)
+        return self.dcb(out, p + "conv.", shortcut=shortcut)
 
 
 class DMCIOracle:
@@ -238,3 +238,165 @@ class DMCIOracle:
         dec.close()
         y_hat = nn.mul_channel(y_hat_so_far, self.sd["q_scale_y_dec"][qp])
         return self.decoder(y_hat, qp)
+
+
+class DMCLDOracle:
+    """CPU restatement of DMCLDProxy (dmc_ld_proxy.cpp:407-593): low-delay inter codec, one
+    picture per call, temporal state = (feature_i | memory, feature_p) + ctx + temporal params.
+    Networks: video_model_ld.py:24-194 (every DepthConvBlock is dcb2)."""
+    CH_SRC, CH_Y, CH_Z, CH_D, CH_M = 192, 128, 128, 256, 256
+
+    def __init__(self, state_dict, skip_thres, cdf_tables=None):
+        self.sd = to_np_state_dict(state_dict)
+        self.net = Net(self.sd)
+        self.skip_thres = float(skip_thres)
+        self.tables = orc_rans.Tables()
+        if cdf_tables is not None:
+            self.tables.set_cdf(cdf_tables[0], cdf_tables[1], 0)
+            self.tables.set_cdf(cdf_tables[2], cdf_tables[3], 1)
+        self.clear()
+        self.debug = {}
+
+    def clear(self):
+        self.feature_i = None        # recon-head output before the shuffle / unshuffled I picture
+        self.memory = None
+        self.feature_p = None
+        self.ctx = None
+        self.temporal = None
+        self.memory_has_value = False
+
+    # ---- sub-networks
+    def _chain(self, x, prefix, n, **last_kw):
+        for i in range(n):
+            x = self.net.dcb(x, prefix + "%d." % i, **(last_kw if i == n - 1 else {}))
+        return x
+
+    def fa_i(self, x):
+        return self._chain(x, "feature_adaptor_i.conv.", 4)
+
+    def fa_m(self, memory, feature):
+        return self._chain(np.concatenate([memory, feature], axis=-1), "feature_adaptor_m.conv.", 4)
+
+    def fe(self, memory):
+        return self._chain(memory, "feature_extractor.conv.", 5)
+
+    def tpe(self, memory):
+        return self.net.rb_stride2(memory, "temporal_prior_encoder.conv.", shortcut=False)
+
+    def encoder(self, xu, ctx, qp):
+        n = self.net
+        out = self._chain(np.concatenate([xu, ctx], axis=-1), "encoder.conv1.", 2)
+        out = n.dcb(out, "encoder.conv2.", q=self.sd["q_encoder"][qp])     # ..._shortcut_with_quant
+        return nn.conv_kxk(out, self.sd["encoder.down.weight"], self.sd["encoder.down.bias"], 3, 2, 1)
+
+    def hyper_encoder(self, y_pad):
+        n = self.net
+        out = n.dcb(y_pad, "hyper_encoder.conv.0.")
+        out = n.rb_stride2(out, "hyper_encoder.conv.1.", shortcut=False)
+        return n.rb_stride2(out, "hyper_encoder.conv.2.", shortcut=False)
+
+    def hyper_decoder(self, z_hat):
+        n = self.net
+        out = n.rb_upsample(z_hat, "hyper_decoder.conv.0.", shortcut=False)
+        out = n.rb_upsample(out, "hyper_decoder.conv.1.", shortcut=False)
+        return n.dcb(out, "hyper_decoder.conv.2.")
+
+    def prior_fusion(self, hyper, temporal_q):
+        out = self._chain(np.concatenate([hyper, temporal_q], axis=-1), "y_prior_fusion.conv.", 3)
+        return self.net.conv1x1(out, "y_prior_fusion.conv.3.")
+
+    def spatial_prior(self, y_hat, common):
+        out = self._chain(np.concatenate([y_hat, common], axis=-1), "y_spatial_prior.conv.", 2)
+        return self.net.conv1x1(out, "y_spatial_prior.conv.2.")
+
+    def decoder(self, y_hat, ctx, qp):
+        up = nn.subpel_conv1x1(y_hat, self.sd["decoder.up.conv.0.weight"])
+        out = self._chain(np.concatenate([up, ctx], axis=-1), "decoder.conv1.", 3)
+        return nn.conv1x1(out, self.sd["decoder.conv2.weight"], self.sd["decoder.conv2.bias"],
+                          q=self.sd["q_decoder"][qp])                        # conv1x1_bias_with_quant
+
+    def recon_head(self, feature):
+        out = self._chain(feature, "recon_head.conv.", 3)
+        head = self.net.conv1x1(out, "recon_head.head.")
+        x_hat = np.clip(nn.pixel_shuffle(head, 8), F16(-0.5), F16(0.5)).astype(F16)
+        return head, x_hat
+
+    # ---- DMCLDProxy::add_ref_feature_from_frame (dmc_ld_proxy.cpp:407-418)
+    def add_ref_feature_from_frame(self, frame, apply_adaptor):
+        """frame: the I codec's reconstruction [H16, W16, 3] fp16."""
+        self.feature_i = nn.pixel_unshuffle(frame.astype(F16), 8)
+        if apply_adaptor:
+            self.memory = self.fa_i(self.feature_i)
+            self.ctx = self.fe(self.memory)
+            self.temporal = self.tpe(self.memory)
+        self.memory_has_value = bool(apply_adaptor)
+
+    def _priors(self, z_hat, qp):
+        hyper = self.hyper_decoder(z_hat)
+        hyper = hyper[:self.temporal.shape[0], :self.temporal.shape[1]]
+        temporal_q = nn.mul_channel(self.temporal, self.sd["q_feature"][qp])
+        common = self.prior_fusion(hyper, temporal_q)
+        C = self.CH_Y
+        return common, common[..., :C], common[..., C:2 * C], common[..., 2 * C:]
+
+    # ---- DMCLDProxy::compress (dmc_ld_proxy.cpp:420-473)
+    def compress(self, x, qp, reset_feature_memory):
+        H, W, _ = x.shape
+        pr, pb = get_padding_size(H, W, 16)
+        xu = nn.pixel_unshuffle(replicate_pad(x.astype(F16), pb, pr), 8)
+        y = self.encoder(xu, self.ctx, qp)
+        yH, yW, C = y.shape
+        pr4, pb4 = get_padding_size(yH, yW, 4)
+        z = self.hyper_encoder(replicate_pad(y, pb4, pr4))
+        z_hat, z_i8 = sym.round_z(z)
+        common, q_dec, scales, means = self._priors(z_hat, qp)
+        y = sym.divide_with_clamp(y, q_dec)
+        mask_0, mask_1 = sym.get_mask_2x(yH, yW, C)
+        y_q0, y_hat0 = sym.process_with_mask_2x(y, scales, means, mask_0, self.skip_thres)
+        means1 = self.spatial_prior(y_hat0, common)
+        y_q1, y_hat1 = sym.process_with_mask_2x(y, scales, means1, mask_1, self.skip_thres)
+        y_q = (y_q0 + y_q1).astype(F16)
+        y_hat = ((y_hat0 + y_hat1).astype(F16) * sym.clamp_min_half(q_dec)).astype(F16)
+        comb, keep = sym.build_index_enc(y_q, scales, self.skip_thres)
+        y_sym = comb[keep]
+        ec = compute_ec_parallel(len(y_sym))
+        stream = orc_rans.encode(self.tables, [("y", y_sym), ("z", z_i8.reshape(-1), qp * self.CH_Z, self.CH_Z)], ec)
+        self.debug = dict(y=y, y_hat=y_hat, z_i8=z_i8, y_sym=y_sym)
+        # lambda_enc_1: decoder, state update
+        self.feature_p = self.decoder(y_hat, self.ctx, qp)
+        if reset_feature_memory:
+            head, _ = self.recon_head(self.feature_p)
+            self.memory = self.fa_i(head)
+        else:
+            self.memory = self.fa_m(self.memory, self.feature_p)
+        self.ctx = self.fe(self.memory)
+        self.temporal = self.tpe(self.memory)
+        return dict(bit_stream=stream.tobytes(), ec_parallel=ec)
+
+    # ---- DMCLDProxy::decompress (dmc_ld_proxy.cpp:475-593)
+    def decompress(self, bit_stream, qp, height, width, ec_parallel, reset_feature_memory):
+        C = self.CH_Y
+        zH, zW = (height + 63) // 64, (width + 63) // 64
+        if self.memory_has_value:
+            self.memory = self.fa_m(self.memory, self.feature_p)
+        else:
+            self.memory = self.fa_i(self.feature_i)
+        self.temporal = self.tpe(self.memory)
+        dec = orc_rans.Decoder(self.tables, np.frombuffer(bit_stream, dtype=np.uint8), ec_parallel)
+        z_i8 = dec.decode_z(self.CH_Z * zH * zW, qp * self.CH_Z, self.CH_Z).reshape(zH, zW, self.CH_Z)
+        common, q_dec, scales, means = self._priors(z_i8.astype(F16), qp)
+        yH, yW = scales.shape[:2]
+        idx, keep = sym.build_index_dec(scales, self.skip_thres)
+        decoded = dec.decode_y(idx[keep])
+        dec.close()
+        self.ctx = self.fe(self.memory)
+        y_q_r = sym.recover(decoded, keep, (yH, yW, C))
+        mask_0, mask_1 = sym.get_mask_2x(yH, yW, C)
+        y_hat = sym.restore_y(y_q_r, means, mask_0)
+        means1 = self.spatial_prior(y_hat, common)
+        y_hat = ((sym.restore_y(y_q_r, means1, mask_1) + y_hat).astype(F16) * sym.clamp_min_half(q_dec)).astype(F16)
+        self.feature_p = self.decoder(y_hat, self.ctx, qp)
+        head, x_hat = self.recon_head(self.feature_p)
+        self.feature_i = head
+        self.memory_has_value = not reset_feature_memory
+        return x_hat

@@ -117,3 +117,44 @@ def round_z(z):
     v = round_half_away(z)
     v = np.minimum(np.maximum(v, np.float32(-64)), np.float32(63))
     return v.astype(F16), v.astype(np.int8)
+
+
+# ------------------------------------------------------------------ 2x checkerboard (inter LD / HT-S)
+def get_mask_2x(H, W, C):
+    """mask_0 = cat(m0, m1), mask_1 = cat(m1, m0) over the two channel halves
+    (dmc_ld_proxy.cpp:672-683 == common_model.py:157-172)."""
+    hh = np.arange(H)[:, None] & 1
+    ww = np.arange(W)[None, :] & 1
+    m0 = (hh == ww)
+    m1 = ~m0
+    half = C // 2
+    mk0 = np.zeros((H, W, C), dtype=bool)
+    mk1 = np.zeros((H, W, C), dtype=bool)
+    mk0[:, :, :half] = m0[:, :, None]
+    mk0[:, :, half:] = m1[:, :, None]
+    mk1[:, :, :half] = m1[:, :, None]
+    mk1[:, :, half:] = m0[:, :, None]
+    return mk0, mk1
+
+
+def clamp_min_half(q):
+    """max(q, 0.5) in fp16 (stream.cu:60-61,437-438)."""
+    return np.maximum(q.astype(F16), F16(0.5)).astype(F16)
+
+
+def divide_with_clamp(y, q):
+    """y * rcp(max(q, 0.5)), stream.cu:422-443; rcp taken as the correctly rounded fp16
+    reciprocal, then one fp16 multiply."""
+    r = (np.float32(1.0) / clamp_min_half(q).astype(np.float32)).astype(F16)
+    return (y.astype(F16) * r).astype(F16)
+
+
+def process_with_mask_2x(y, scales, means, mask, thres):
+    """process_with_mask_kernel<scale_out=false> (stream.cu:549-630): y_q, y_hat."""
+    y_q, y_hat, _ = process_with_mask(y, scales, means, mask, thres)
+    return y_q, y_hat
+
+
+def restore_y(y_q_r, means, mask):
+    """restore_y_kernel (stream.cu:686-729): (y + means) * mask."""
+    return np.where(mask, (y_q_r + means).astype(F16), F16(0)).astype(F16)

@@ -18,9 +18,35 @@ def dmci_model(seed=0, skip_thres=0.0):
     return _CACHE[key]
 
 
+def dmc_ld_model(seed=0, skip_thres=0.0):
+    """Seeded synthetic low-delay inter model (CPU, fp32 parameters) with its CDF tables."""
+    key = ("ld", seed, skip_thres)
+    if key not in _CACHE:
+        m = models.DMC()
+        m.load_state_dict(synthetic.synthetic_state_dict(arch.dmc_ld_spec(), seed))
+        m.update(skip_thres)
+        _CACHE[key] = m
+    return _CACHE[key]
+
+
 def oracle_for(model):
     from oracle import codec
-    return codec.DMCIOracle(model.state_dict(), model.skip_thres, model.get_cdf_info())
+    cls = codec.DMCLDOracle if isinstance(model, models.DMC) else codec.DMCIOracle
+    return cls(model.state_dict(), model.skip_thres, model.get_cdf_info())
+
+
+def force_ld_state(o, feature, memory):
+    """Loads the reference graph's temporal state (tests/golden/dmcld_golden.npz) into an LD
+    oracle: memory=None means the previous picture reset the feature memory."""
+    if memory is None:
+        o.feature_i = feature
+        o.memory = o.fa_i(feature)
+        o.memory_has_value = False
+    else:
+        o.memory = o.fa_m(memory, feature)
+        o.memory_has_value = True
+    o.ctx = o.fe(o.memory)
+    o.temporal = o.tpe(o.memory)
 
 
 def picture(height, width, index=0, seed=0):

@@ -63,6 +63,69 @@ def test_oracle_closure(hw, qp):
     assert r["x_hat"].shape == ((hw[0] + 15) // 16 * 16, (hw[1] + 15) // 16 * 16, 3)
 
 
+# ------------------------------------------------------------------------------ inter model (LD)
+@pytest.fixture(scope="module")
+def golden_ld(golden_dir):
+    return np.load(os.path.join(golden_dir, "dmcld_golden.npz"))
+
+
+def test_ld_parameter_inventory():
+    from dcvc_amd import arch
+    spec = arch.dmc_ld_spec()
+    assert arch.param_count(spec) == 9650176           # strict=True load in make_dmcld_golden.py
+    assert spec["temporal_prior_encoder.conv.down.weight"] == (256, 1024, 1, 1)
+    assert spec["decoder.up.conv.0.weight"] == (1024, 128, 1, 1)
+
+
+def test_ld_oracle_follows_reference_graph(golden_ld):
+    """Every P picture on its own, started from the reference graph's temporal state (memory +
+    reference feature after the previous picture), incl. the picture after a memory reset: the
+    reconstruction must equal the reference's fp32 forward_one_frame up to fp16 noise."""
+    from codec_util import dmc_ld_model, force_ld_state
+    from oracle import codec
+    g = golden_ld
+    m = dmc_ld_model()
+    for s in range(2):
+        plan = g["s%d_plan" % s]
+        for i in range(len(plan)):
+            qp, reset = int(plan[i][0]), bool(plan[i][1])
+            o = codec.DMCLDOracle(m.state_dict(), -60000.0, m.get_cdf_info())
+            if i == 0:
+                o.add_ref_feature_from_frame(g["s%d_ref" % s], True)
+            else:
+                key = "s%d_mem%d" % (s, i - 1)
+                force_ld_state(o, g["s%d_feat%d" % (s, i - 1)], g[key] if key in g else None)
+            o.compress(g["s%d_x%d" % (s, i)], qp, reset)
+            _, x_hat = o.recon_head(o.feature_p)
+            ref = np.clip(g["s%d_xhat%d" % (s, i)].astype(np.float32), -0.5, 0.5)
+            p = psnr(x_hat, ref)
+            print("seq", s, "picture", i, "PSNR oracle vs reference graph: %.2f dB" % p)
+            assert p > 47.0
+
+
+def test_ld_oracle_sequence_closure(golden_ld):
+    """Free-running encoder and decoder oracles over a sequence with a reset: identical temporal
+    state on both sides, decoded pictures track the reference graph."""
+    from codec_util import dmc_ld_model, oracle_for
+    g = golden_ld
+    m = dmc_ld_model(skip_thres=0.15)
+    enc, dec = oracle_for(m), oracle_for(m)
+    ref = g["s0_ref"]
+    enc.add_ref_feature_from_frame(ref, True)
+    dec.add_ref_feature_from_frame(ref, False)
+    for i, (qp, reset) in enumerate(g["s0_plan"]):
+        x = g["s0_x%d" % i]
+        r = enc.compress(x, int(qp), bool(reset))
+        xd = dec.decompress(r["bit_stream"], int(qp), x.shape[0], x.shape[1], r["ec_parallel"], bool(reset))
+        assert np.array_equal(dec.feature_p, enc.feature_p)
+        _, xe = enc.recon_head(enc.feature_p)
+        assert np.array_equal(xd, xe)
+        # skip mode (inference only) zeroes low-scale symbols, so only a loose bound holds here
+        p = psnr(xd, np.clip(g["s0_xhat%d" % i].astype(np.float32), -0.5, 0.5))
+        print("picture", i, "bytes", len(r["bit_stream"]), "PSNR vs graph %.2f dB" % p)
+        assert p > 20.0
+
+
 def test_mfma_model_matches_hardware_measurements(golden_dir):
     """The oracle's contraction arithmetic against v_mfma_f32_32x32x16_f16 outputs recorded on an
     MI355X (tools/mfma_probe2.hip): every trial bit-exact."""
