@@ -1,5 +1,6 @@
 // C ABI of the picture codecs (include/dcvc_amd_codec.h).
 #include "capi_common.h"
+#include "codec/dmc_ld.h"
 #include "codec/dmci.h"
 #include "dcvc_amd_codec.h"
 
@@ -8,6 +9,34 @@
 struct dcvc_dmci {
     dcvc::DmciCodec codec;
 };
+
+struct dcvc_dmcld {
+    dcvc::DmcLdCodec codec;
+};
+
+namespace {
+
+dcvc::ParamStore make_store(int n, const char* const* names, const void* const* data, const int* dtypes,
+                            const int* ndims, const int64_t* dims)
+{
+    dcvc::ParamStore ps;
+    const int64_t* d = dims;
+    for (int i = 0; i < n; ++i) {
+        ps.add(names[i], data[i], dtypes[i], d, ndims[i]);
+        d += ndims[i];
+    }
+    return ps;
+}
+
+void check_padding16(int height, int width, int padding_b, int padding_r)
+{
+    const int pb = (height + 15) / 16 * 16 - height, pr = (width + 15) / 16 * 16 - width;
+    if (padding_b != pb || padding_r != pr) {
+        throw std::invalid_argument("compress: padding must extend the picture to multiples of 16");
+    }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -27,13 +56,7 @@ int dcvc_dmci_set_param(dcvc_dmci* c, int n, const char* const* names, const voi
                         const int* dtypes, const int* ndims, const int64_t* dims, float skip_thres)
 {
     return dcvc::guarded([&] {
-        dcvc::ParamStore ps;
-        const int64_t* d = dims;
-        for (int i = 0; i < n; ++i) {
-            ps.add(names[i], data[i], dtypes[i], d, ndims[i]);
-            d += ndims[i];
-        }
-        c->codec.set_param(ps, skip_thres);
+        c->codec.set_param(make_store(n, names, data, dtypes, ndims, dims), skip_thres);
     });
 }
 
@@ -42,10 +65,7 @@ int dcvc_dmci_compress(dcvc_dmci* c, const void* x, int height, int width, int q
 {
     int ec = -1;
     const int rc = dcvc::guarded([&] {
-        const int pb = (height + 15) / 16 * 16 - height, pr = (width + 15) / 16 * 16 - width;
-        if (padding_b != pb || padding_r != pr) {
-            throw std::invalid_argument("compress: padding must extend the picture to multiples of 16");
-        }
+        check_padding16(height, width, padding_b, padding_r);
         ec = c->codec.compress(static_cast<const dcvc::half_t*>(x), height, width, qp,
                                static_cast<dcvc::half_t*>(x_hat), static_cast<hipStream_t>(stream));
     });
@@ -74,6 +94,79 @@ int dcvc_dmci_set_use_graphs(dcvc_dmci* c, int on)
 }
 
 int64_t dcvc_dmci_debug_read(dcvc_dmci* c, const char* name, void* dst, size_t cap, void* stream)
+{
+    int64_t n = -1;
+    const int rc = dcvc::guarded([&] {
+        n = static_cast<int64_t>(c->codec.debug_read(name, dst, cap, static_cast<hipStream_t>(stream)));
+    });
+    return rc < 0 ? rc : n;
+}
+
+// ------------------------------------------------------------------------------------ DMC-LD
+dcvc_dmcld* dcvc_dmcld_create(void)
+{
+    dcvc_dmcld* c = nullptr;
+    dcvc::guarded([&] { c = new dcvc_dmcld(); });
+    return c;
+}
+
+void dcvc_dmcld_destroy(dcvc_dmcld* c)
+{
+    delete c;
+}
+
+int dcvc_dmcld_set_param(dcvc_dmcld* c, int n, const char* const* names, const void* const* data,
+                         const int* dtypes, const int* ndims, const int64_t* dims, float skip_thres)
+{
+    return dcvc::guarded([&] {
+        c->codec.set_param(make_store(n, names, data, dtypes, ndims, dims), skip_thres);
+    });
+}
+
+int dcvc_dmcld_add_ref_feature_from_frame(dcvc_dmcld* c, const void* frame, int height, int width,
+                                          int apply_adaptor, void* stream)
+{
+    return dcvc::guarded([&] {
+        c->codec.add_ref_feature_from_frame(static_cast<const dcvc::half_t*>(frame), height, width,
+                                            apply_adaptor != 0, static_cast<hipStream_t>(stream));
+    });
+}
+
+int dcvc_dmcld_compress(dcvc_dmcld* c, const void* x, int height, int width, int qp,
+                        int reset_feature_memory, int padding_b, int padding_r, void* stream)
+{
+    int ec = -1;
+    const int rc = dcvc::guarded([&] {
+        check_padding16(height, width, padding_b, padding_r);
+        ec = c->codec.compress(static_cast<const dcvc::half_t*>(x), height, width, qp,
+                               reset_feature_memory != 0, static_cast<hipStream_t>(stream));
+    });
+    return rc < 0 ? rc : ec;
+}
+
+int64_t dcvc_dmcld_get_stream(dcvc_dmcld* c, uint8_t* dst, size_t cap)
+{
+    const auto& s = c->codec.stream_bytes();
+    if (dst != nullptr) std::memcpy(dst, s.data(), s.size() < cap ? s.size() : cap);
+    return static_cast<int64_t>(s.size());
+}
+
+int dcvc_dmcld_decompress(dcvc_dmcld* c, const uint8_t* bit_stream, size_t nbytes, int qp, int height,
+                          int width, int ec_parallel, int reset_feature_memory, void* x_hat,
+                          void* stream)
+{
+    return dcvc::guarded([&] {
+        c->codec.decompress(bit_stream, nbytes, qp, height, width, ec_parallel, reset_feature_memory != 0,
+                            static_cast<dcvc::half_t*>(x_hat), static_cast<hipStream_t>(stream));
+    });
+}
+
+int dcvc_dmcld_set_use_graphs(dcvc_dmcld* c, int on)
+{
+    return dcvc::guarded([&] { c->codec.set_use_graphs(on != 0); });
+}
+
+int64_t dcvc_dmcld_debug_read(dcvc_dmcld* c, const char* name, void* dst, size_t cap, void* stream)
 {
     int64_t n = -1;
     const int rc = dcvc::guarded([&] {

@@ -1,0 +1,153 @@
+// See codec_base.h.
+#include "codec/codec_base.h"
+
+namespace dcvc {
+
+CodecBase::CodecBase()
+{
+    int lo = 0, hi = 0;
+    hip_check(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
+    hip_check(hipStreamCreateWithPriority(&m_io_stream, hipStreamNonBlocking, hi), "hipStreamCreate(io)");
+    hip_check(hipStreamCreateWithFlags(&m_cs, hipStreamNonBlocking), "hipStreamCreate(compute)");
+    hip_check(hipEventCreateWithFlags(&m_ev_job, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&m_ev_in, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&m_ev_out, hipEventDisableTiming), "hipEventCreate");
+    m_worker = std::thread(&CodecBase::worker_loop, this);
+}
+
+CodecBase::~CodecBase()
+{
+    {
+        std::lock_guard<std::mutex> lk(m_mu);
+        m_stop = true;
+    }
+    m_cv_work.notify_all();
+    if (m_worker.joinable()) m_worker.join();
+    clear_graphs();
+    if (m_cs) (void)hipStreamSynchronize(m_cs);
+    if (m_ev_job) (void)hipEventDestroy(m_ev_job);
+    if (m_ev_in) (void)hipEventDestroy(m_ev_in);
+    if (m_ev_out) (void)hipEventDestroy(m_ev_out);
+    if (m_cs) (void)hipStreamDestroy(m_cs);
+    if (m_io_stream) (void)hipStreamDestroy(m_io_stream);
+}
+
+void CodecBase::clear_graphs()
+{
+    for (auto& kv : m_graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    }
+    m_graphs.clear();
+}
+
+void CodecBase::quiesce()
+{
+    {
+        std::unique_lock<std::mutex> lk(m_mu);
+        m_cv_done.wait(lk, [&] { return m_done && !m_pending; });
+    }
+    if (m_cs) (void)hipStreamSynchronize(m_cs);
+    if (m_io_stream) (void)hipStreamSynchronize(m_io_stream);
+}
+
+void CodecBase::bind_stage_arg(int key, const void* arg)
+{
+    GraphSlot& slot = m_graphs[key];
+    if (slot.exec && slot.arg != arg) {
+        (void)hipGraphExecDestroy(slot.exec);
+        slot.exec = nullptr;
+    }
+    slot.arg = arg;
+}
+
+hipStream_t CodecBase::enter(hipStream_t user)
+{
+    hip_check(hipEventRecord(m_ev_in, user), "hipEventRecord(in)");
+    hip_check(hipStreamWaitEvent(m_cs, m_ev_in, 0), "hipStreamWaitEvent(in)");
+    return m_cs;
+}
+
+void CodecBase::leave(hipStream_t user)
+{
+    hip_check(hipEventRecord(m_ev_out, m_cs), "hipEventRecord(out)");
+    hip_check(hipStreamWaitEvent(user, m_ev_out, 0), "hipStreamWaitEvent(out)");
+}
+
+void CodecBase::submit(hipStream_t st, std::function<void()> job)
+{
+    hip_check(hipEventRecord(m_ev_job, st), "hipEventRecord(job)");
+    hip_check(hipStreamWaitEvent(m_io_stream, m_ev_job, 0), "hipStreamWaitEvent(job)");
+    {
+        std::lock_guard<std::mutex> lk(m_mu);
+        m_job = std::move(job);
+        m_pending = true;
+        m_done = false;
+        m_worker_error.clear();
+    }
+    m_cv_work.notify_one();
+}
+
+void CodecBase::wait_job()
+{
+    std::unique_lock<std::mutex> lk(m_mu);
+    m_cv_done.wait(lk, [&] { return m_done; });
+    if (!m_worker_error.empty()) throw std::runtime_error("entropy worker: " + m_worker_error);
+}
+
+void CodecBase::worker_loop()
+{
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::unique_lock<std::mutex> lk(m_mu);
+            m_cv_work.wait(lk, [&] { return m_pending || m_stop; });
+            if (m_stop) return;
+            m_pending = false;
+            job = std::move(m_job);
+        }
+        std::string err;
+        try {
+            job();
+        } catch (const std::exception& e) {
+            err = e.what();
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_mu);
+            m_worker_error = err;
+            m_done = true;
+        }
+        m_cv_done.notify_all();
+    }
+}
+
+void CodecBase::load_cdf_tables(const ParamStore& ps)
+{
+    auto cdf = [&](const char* name_cdf, const char* name_len, int index) {
+        const HostTensor& c = ps.at(name_cdf);
+        const HostTensor& l = ps.at(name_len);
+        const int num = static_cast<int>(l.numel());
+        const int stride = static_cast<int>(c.numel() / num);
+        m_enc.set_cdf(c.i.data(), num, stride, l.i.data(), index);
+        m_dec.set_cdf(c.i.data(), num, stride, l.i.data(), index);
+    };
+    cdf("bit_estimator_z.quantized_cdf", "bit_estimator_z.cdf_length", 0);
+    cdf("gaussian_encoder.quantized_cdf", "gaussian_encoder.cdf_length", 1);
+}
+
+const half_t* CodecBase::upload_qp_table(const ParamStore& ps, DeviceArena& mem, const char* name, int ch)
+{
+    const HostTensor& t = ps.at(name);
+    if (t.shape.size() != 2 || t.shape[0] != kQpNum || t.shape[1] != ch) {
+        throw std::invalid_argument(std::string("unexpected shape for ") + name);
+    }
+    return mem.upload(t.h);
+}
+
+void CodecBase::copy_qp_row(half_t* dst, const half_t* table, int qp, int ch, hipStream_t st)
+{
+    if (qp < 0 || qp >= kQpNum) throw std::invalid_argument("qp out of range [0, 63]");
+    hip_check(hipMemcpyAsync(dst, table + static_cast<size_t>(qp) * ch, ch * sizeof(half_t),
+                             hipMemcpyDeviceToDevice, st), "select qp");
+}
+
+}  // namespace dcvc

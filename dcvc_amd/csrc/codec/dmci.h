@@ -2,19 +2,13 @@
 // (src/layers/extensions/inference/dmci_proxy.{h,cpp}): set_param / compress / decompress.
 #pragma once
 
-#include "codec/modules.h"
-#include "rans/rans_coder.h"
-
-#include <condition_variable>
-#include <mutex>
-#include <thread>
+#include "codec/codec_base.h"
 
 namespace dcvc {
 
-class DmciCodec {
+class DmciCodec : public CodecBase {
 public:
     static constexpr int kChSrc = 192, kChEncDec = 384, kChY = 256, kChZ = 128;   // image_model.py:15-18
-    static constexpr int kQpNum = 64;
 
     DmciCodec();
     ~DmciCodec();
@@ -27,7 +21,6 @@ public:
     // stream_bytes() when the call returns; the reconstruction kernels may still be running on
     // `stream` (as in the reference, the harness synchronises).
     int compress(const half_t* x, int height, int width, int qp, half_t* x_hat, hipStream_t stream);
-    const std::vector<uint8_t>& stream_bytes() const { return m_enc.stream(); }
 
     // dmci_proxy.cpp:423-602
     void decompress(const uint8_t* bits, size_t nbytes, int qp, int height, int width, int ec_parallel,
@@ -35,8 +28,6 @@ public:
 
     // test hook: copies an internal tensor of the last call to the host. Returns the byte size.
     size_t debug_read(const std::string& name, void* dst, size_t cap, hipStream_t stream);
-
-    void set_use_graphs(bool on) { m_use_graphs = on; }
 
 private:
     struct Geometry {
@@ -51,8 +42,6 @@ private:
     };
 
     void prepare(int height, int width);
-    hipStream_t enter(hipStream_t user);
-    void leave(hipStream_t user);
     void select_qp(int qp, hipStream_t st);
     // network stages
     void run_encoder(hipStream_t st);                       // U -> Y
@@ -62,18 +51,13 @@ private:
     void run_decoder(half_t* x_hat, hipStream_t st);        // YHAT -> x_hat
     void enc_stage0(hipStream_t st);
     void entropy_encode(int qp);                            // worker thread
-    void worker_loop();
-
-    template <typename F>
-    void run_stage(int key, hipStream_t st, F&& fn);
-    void clear_graphs();
 
     // ---- parameters
     DeviceArena m_wmem;
-    half_t* m_q_enc = nullptr;      // [64][384]
-    half_t* m_q_dec = nullptr;
-    half_t* m_q_y_enc = nullptr;    // [64][256]
-    half_t* m_q_y_dec = nullptr;
+    const half_t* m_q_enc = nullptr;      // [64][384]
+    const half_t* m_q_dec = nullptr;
+    const half_t* m_q_y_enc = nullptr;    // [64][256]
+    const half_t* m_q_y_dec = nullptr;
     half_t* m_zeros = nullptr;
     DcbW m_enc1, m_enc2[6];
     ConvKW m_enc_down;
@@ -106,35 +90,12 @@ private:
     int8_t* m_DECODED = nullptr;
     int32_t *m_CNT = nullptr, *m_TOTALS = nullptr;
     // pinned host staging
-    int32_t* m_h_totals = nullptr;
-    int16_t* m_h_sym = nullptr;
-    int8_t* m_h_z = nullptr;
-    uint8_t* m_h_idx = nullptr;
-    int8_t* m_h_dec = nullptr;
-    size_t m_h_cap = 0;
-
-    // ---- entropy coding
-    RansEncoder m_enc;
-    RansDecoder m_dec;
-    hipStream_t m_io_stream = nullptr;
-    hipStream_t m_cs = nullptr;           // the codec's compute stream
-    hipEvent_t m_ev_y = nullptr, m_ev_in = nullptr, m_ev_out = nullptr;
-    std::thread m_worker;
-    std::mutex m_mu;
-    std::condition_variable m_cv_work, m_cv_done;
-    bool m_pending = false, m_done = false, m_stop = false;
-    int m_pending_qp = 0;
+    Pinned<int32_t> m_h_totals;
+    Pinned<int16_t> m_h_sym;
+    Pinned<int8_t> m_h_z;
+    Pinned<uint8_t> m_h_idx;
+    Pinned<int8_t> m_h_dec;
     int m_ec_parallel = 1;
-    std::string m_worker_error;
-
-    // ---- graphs
-    bool m_use_graphs = true;
-    struct GraphSlot {
-        hipGraphExec_t exec = nullptr;
-        bool warmed = false;
-        const void* arg = nullptr;      // pointer argument baked into the capture (x_hat)
-    };
-    std::map<int, GraphSlot> m_graphs;
 };
 
 }  // namespace dcvc

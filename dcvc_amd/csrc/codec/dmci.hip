@@ -13,51 +13,13 @@ namespace {
 
 enum StageKey : int { kEnc0 = 0, kEnc1 = 1, kDec0 = 10, kDec1 = 11 };
 
-constexpr int kMinSymbolsPerStream = 32768;   // def_const.h:18
-
-int ceil_div(int a, int b) { return (a + b - 1) / b; }
-
 }  // namespace
 
-DmciCodec::DmciCodec()
-{
-    int lo = 0, hi = 0;
-    hip_check(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
-    hip_check(hipStreamCreateWithPriority(&m_io_stream, hipStreamNonBlocking, hi), "hipStreamCreate(io)");
-    hip_check(hipStreamCreateWithFlags(&m_cs, hipStreamNonBlocking), "hipStreamCreate(compute)");
-    hip_check(hipEventCreateWithFlags(&m_ev_y, hipEventDisableTiming), "hipEventCreate");
-    hip_check(hipEventCreateWithFlags(&m_ev_in, hipEventDisableTiming), "hipEventCreate");
-    hip_check(hipEventCreateWithFlags(&m_ev_out, hipEventDisableTiming), "hipEventCreate");
-    m_worker = std::thread(&DmciCodec::worker_loop, this);
-}
+DmciCodec::DmciCodec() = default;
 
 DmciCodec::~DmciCodec()
 {
-    {
-        std::lock_guard<std::mutex> lk(m_mu);
-        m_stop = true;
-    }
-    m_cv_work.notify_all();
-    if (m_worker.joinable()) m_worker.join();
-    clear_graphs();
-    if (m_h_totals) (void)hipHostFree(m_h_totals);
-    if (m_h_sym) (void)hipHostFree(m_h_sym);
-    if (m_h_z) (void)hipHostFree(m_h_z);
-    if (m_h_idx) (void)hipHostFree(m_h_idx);
-    if (m_h_dec) (void)hipHostFree(m_h_dec);
-    if (m_ev_y) (void)hipEventDestroy(m_ev_y);
-    if (m_ev_in) (void)hipEventDestroy(m_ev_in);
-    if (m_ev_out) (void)hipEventDestroy(m_ev_out);
-    if (m_cs) (void)hipStreamDestroy(m_cs);
-    if (m_io_stream) (void)hipStreamDestroy(m_io_stream);
-}
-
-void DmciCodec::clear_graphs()
-{
-    for (auto& kv : m_graphs) {
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    }
-    m_graphs.clear();
+    quiesce();
 }
 
 // ------------------------------------------------------------------------------------ set_param
@@ -67,17 +29,10 @@ void DmciCodec::set_param(const ParamStore& ps, float skip_thres)
     m_wmem.release();
     kernels_init();
     m_skip_thres = skip_thres;
-    auto table = [&](const char* name, int ch) {
-        const HostTensor& t = ps.at(name);
-        if (t.shape.size() != 2 || t.shape[0] != kQpNum || t.shape[1] != ch) {
-            throw std::invalid_argument(std::string("unexpected shape for ") + name);
-        }
-        return m_wmem.upload(t.h);
-    };
-    m_q_enc = table("q_scale_enc", kChEncDec);
-    m_q_dec = table("q_scale_dec", kChEncDec);
-    m_q_y_enc = table("q_scale_y_enc", kChY);
-    m_q_y_dec = table("q_scale_y_dec", kChY);
+    m_q_enc = upload_qp_table(ps, m_wmem, "q_scale_enc", kChEncDec);
+    m_q_dec = upload_qp_table(ps, m_wmem, "q_scale_dec", kChEncDec);
+    m_q_y_enc = upload_qp_table(ps, m_wmem, "q_scale_y_enc", kChY);
+    m_q_y_dec = upload_qp_table(ps, m_wmem, "q_scale_y_dec", kChY);
     m_zeros = m_wmem.alloc_half(2048);
     m_cur_q_enc = m_wmem.alloc_half(kChEncDec);
     m_cur_q_dec = m_wmem.alloc_half(kChEncDec);
@@ -105,16 +60,7 @@ void DmciCodec::set_param(const ParamStore& ps, float skip_thres)
     for (int i = 0; i < 12; ++i) m_dec1[i].load(ps, m_wmem, "dec.dec_1." + std::to_string(i + 1) + ".");
     m_dec2.load(ps, m_wmem, "dec.dec_2.");
 
-    auto cdf = [&](const char* name_cdf, const char* name_len, int index) {
-        const HostTensor& c = ps.at(name_cdf);
-        const HostTensor& l = ps.at(name_len);
-        const int num = static_cast<int>(l.numel());
-        const int stride = static_cast<int>(c.numel() / num);
-        m_enc.set_cdf(c.i.data(), num, stride, l.i.data(), index);
-        m_dec.set_cdf(c.i.data(), num, stride, l.i.data(), index);
-    };
-    cdf("bit_estimator_z.quantized_cdf", "bit_estimator_z.cdf_length", 0);
-    cdf("gaussian_encoder.quantized_cdf", "gaussian_encoder.cdf_length", 1);
+    load_cdf_tables(ps);
     m_has_params = true;
 }
 
@@ -158,68 +104,19 @@ void DmciCodec::prepare(int height, int width)
     m_DECODED = static_cast<int8_t*>(m_bmem.alloc(4 * nq));
     m_CNT = static_cast<int32_t*>(m_bmem.alloc(sizeof(int32_t) * symbol_blocks(static_cast<int>(nq))));
     m_TOTALS = static_cast<int32_t*>(m_bmem.alloc(sizeof(int32_t) * 4));
-    if (m_h_cap < 4 * nq || !m_h_totals) {
-        if (m_h_totals) (void)hipHostFree(m_h_totals);
-        if (m_h_sym) (void)hipHostFree(m_h_sym);
-        if (m_h_z) (void)hipHostFree(m_h_z);
-        if (m_h_idx) (void)hipHostFree(m_h_idx);
-        if (m_h_dec) (void)hipHostFree(m_h_dec);
-        m_h_cap = 4 * nq;
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&m_h_totals), 64, hipHostMallocDefault), "hipHostMalloc");
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&m_h_sym), m_h_cap * 2, hipHostMallocDefault), "hipHostMalloc");
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&m_h_z), P64 * kChZ + 64, hipHostMallocDefault), "hipHostMalloc");
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&m_h_idx), m_h_cap, hipHostMallocDefault), "hipHostMalloc");
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&m_h_dec), m_h_cap, hipHostMallocDefault), "hipHostMalloc");
-    } else {
-        // the z staging buffer depends on the resolution too
-        (void)hipHostFree(m_h_z);
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&m_h_z), P64 * kChZ + 64, hipHostMallocDefault), "hipHostMalloc");
-    }
+    m_h_totals.reserve(16);
+    m_h_sym.reserve(4 * nq);
+    m_h_z.reserve(P64 * kChZ + 64);
+    m_h_idx.reserve(4 * nq);
+    m_h_dec.reserve(4 * nq);
 }
 
 void DmciCodec::select_qp(int qp, hipStream_t st)
 {
-    if (qp < 0 || qp >= kQpNum) throw std::invalid_argument("qp out of range [0, 63]");
-    auto cp = [&](half_t* dst, const half_t* table, int ch) {
-        hip_check(hipMemcpyAsync(dst, table + static_cast<size_t>(qp) * ch, ch * sizeof(half_t),
-                                 hipMemcpyDeviceToDevice, st), "select_qp");
-    };
-    cp(m_cur_q_enc, m_q_enc, kChEncDec);
-    cp(m_cur_q_dec, m_q_dec, kChEncDec);
-    cp(m_cur_q_y_enc, m_q_y_enc, kChY);
-    cp(m_cur_q_y_dec, m_q_y_dec, kChY);
-}
-
-// ------------------------------------------------------------------------------------ graphs
-template <typename F>
-void DmciCodec::run_stage(int key, hipStream_t st, F&& fn)
-{
-    if (!m_use_graphs) {
-        fn();
-        return;
-    }
-    GraphSlot& slot = m_graphs[key];
-    if (!slot.warmed) {            // first call runs eagerly: lazy one-time initialisation happens here
-        fn();
-        slot.warmed = true;
-        return;
-    }
-    if (!slot.exec) {
-        hipGraph_t graph = nullptr;
-        hip_check(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-        try {
-            fn();
-        } catch (...) {
-            (void)hipStreamEndCapture(st, &graph);
-            if (graph) (void)hipGraphDestroy(graph);
-            throw;
-        }
-        hip_check(hipStreamEndCapture(st, &graph), "hipStreamEndCapture");
-        const hipError_t e = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        hip_check(e, "hipGraphInstantiate");
-    }
-    hip_check(hipGraphLaunch(slot.exec, st), "hipGraphLaunch");
+    copy_qp_row(m_cur_q_enc, m_q_enc, qp, kChEncDec, st);
+    copy_qp_row(m_cur_q_dec, m_q_dec, qp, kChEncDec, st);
+    copy_qp_row(m_cur_q_y_enc, m_q_y_enc, qp, kChY, st);
+    copy_qp_row(m_cur_q_y_dec, m_q_y_dec, qp, kChY, st);
 }
 
 // ------------------------------------------------------------------------------------ networks
@@ -331,23 +228,6 @@ void DmciCodec::enc_stage0(hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------ compress
-// All codec work runs on the codec's own non-blocking stream, ordered after the caller's stream
-// on entry and before it on exit: graph capture then works whatever stream the caller is on
-// (the legacy default stream cannot capture - the reference harness has to switch streams for
-// that reason, test_video.py:422-425).
-hipStream_t DmciCodec::enter(hipStream_t user)
-{
-    hip_check(hipEventRecord(m_ev_in, user), "hipEventRecord(in)");
-    hip_check(hipStreamWaitEvent(m_cs, m_ev_in, 0), "hipStreamWaitEvent(in)");
-    return m_cs;
-}
-
-void DmciCodec::leave(hipStream_t user)
-{
-    hip_check(hipEventRecord(m_ev_out, m_cs), "hipEventRecord(out)");
-    hip_check(hipStreamWaitEvent(user, m_ev_out, 0), "hipStreamWaitEvent(out)");
-}
-
 int DmciCodec::compress(const half_t* x, int height, int width, int qp, half_t* x_hat, hipStream_t user)
 {
     prepare(height, width);
@@ -355,68 +235,22 @@ int DmciCodec::compress(const half_t* x, int height, int width, int qp, half_t* 
     select_qp(qp, st);
     pad_unshuffle8(x, height, width, 3, m_U, m_g.H8, m_g.W8, st);   // outside the graph: x varies
     run_stage(kEnc0, st, [&] { enc_stage0(st); });
-    hip_check(hipEventRecord(m_ev_y, st), "hipEventRecord");
-    // the io stream's dependency on the symbols is enqueued here, before the next stage may put
-    // the compute stream into capture mode (HIP refuses cross-stream waits on a capturing stream)
-    hip_check(hipStreamWaitEvent(m_io_stream, m_ev_y, 0), "hipStreamWaitEvent");
-    {
-        std::lock_guard<std::mutex> lk(m_mu);
-        m_pending = true;
-        m_done = false;
-        m_pending_qp = qp;
-        m_worker_error.clear();
-    }
-    m_cv_work.notify_one();
+    submit(st, [this, qp] { entropy_encode(qp); });
     // the reconstruction runs on the GPU while the worker thread entropy-codes on the host
-    {
-        GraphSlot& slot = m_graphs[kEnc1];
-        if (slot.exec && slot.arg != x_hat) {          // output pointer is baked into the capture
-            (void)hipGraphExecDestroy(slot.exec);
-            slot.exec = nullptr;
-        }
-        slot.arg = x_hat;
-    }
+    bind_stage_arg(kEnc1, x_hat);
     run_stage(kEnc1, st, [&] { run_decoder(x_hat, st); });
     leave(user);
-    std::unique_lock<std::mutex> lk(m_mu);
-    m_cv_done.wait(lk, [&] { return m_done; });
-    if (!m_worker_error.empty()) throw std::runtime_error("entropy worker: " + m_worker_error);
+    wait_job();
     return m_ec_parallel;
-}
-
-void DmciCodec::worker_loop()
-{
-    for (;;) {
-        int qp;
-        {
-            std::unique_lock<std::mutex> lk(m_mu);
-            m_cv_work.wait(lk, [&] { return m_pending || m_stop; });
-            if (m_stop) return;
-            m_pending = false;
-            qp = m_pending_qp;
-        }
-        std::string err;
-        try {
-            entropy_encode(qp);
-        } catch (const std::exception& e) {
-            err = e.what();
-        }
-        {
-            std::lock_guard<std::mutex> lk(m_mu);
-            m_worker_error = err;
-            m_done = true;
-        }
-        m_cv_done.notify_all();
-    }
 }
 
 void DmciCodec::entropy_encode(int qp)
 {
     // dmci_proxy.cpp:809-845: wait for the symbols, copy them out, code groups 3,2,1,0 then z
     const Geometry& g = m_g;
-    hip_check(hipMemcpyAsync(m_h_totals, m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, m_io_stream), "D2H totals");
+    hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, m_io_stream), "D2H totals");
     const int nz = g.P64() * kChZ;
-    hip_check(hipMemcpyAsync(m_h_z, m_ZI8, nz, hipMemcpyDeviceToHost, m_io_stream), "D2H z");
+    hip_check(hipMemcpyAsync(m_h_z.get(), m_ZI8, nz, hipMemcpyDeviceToHost, m_io_stream), "D2H z");
     hip_check(hipStreamSynchronize(m_io_stream), "sync io");
     int base[4], total = 0;
     for (int k = 0; k < 4; ++k) {
@@ -424,14 +258,14 @@ void DmciCodec::entropy_encode(int qp)
         total += m_h_totals[k];
     }
     if (total > 0) {
-        hip_check(hipMemcpyAsync(m_h_sym, m_COMP, static_cast<size_t>(total) * 2, hipMemcpyDeviceToHost, m_io_stream), "D2H symbols");
+        hip_check(hipMemcpyAsync(m_h_sym.get(), m_COMP, static_cast<size_t>(total) * 2, hipMemcpyDeviceToHost, m_io_stream), "D2H symbols");
         hip_check(hipStreamSynchronize(m_io_stream), "sync io");
     }
-    m_ec_parallel = std::max(1, std::min(kMaxEcParallel, total / kMinSymbolsPerStream));   // dmc_common.cpp:31-35
+    m_ec_parallel = ec_parallel_for(total);
     m_enc.reset();
     m_enc.set_parallel(m_ec_parallel);
-    for (int k = 3; k >= 0; --k) m_enc.push_y(m_h_sym + base[k], m_h_totals[k]);
-    m_enc.push_z(m_h_z, nz, qp * kChZ, kChZ);
+    for (int k = 3; k >= 0; --k) m_enc.push_y(m_h_sym.get() + base[k], m_h_totals[k]);
+    m_enc.push_z(m_h_z.get(), nz, qp * kChZ, kChZ);
     m_enc.flush();
 }
 
@@ -447,8 +281,8 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
     m_dec.set_stream(bits, nbytes);
     const int nz = g.P64() * kChZ;
     const int nq = g.P16() * (kChY / 4);
-    m_dec.decode_z(nz, qp * kChZ, kChZ, m_h_z);
-    hip_check(hipMemcpyAsync(m_ZI8, m_h_z, nz, hipMemcpyHostToDevice, st), "H2D z");
+    m_dec.decode_z(nz, qp * kChZ, kChZ, m_h_z.get());
+    hip_check(hipMemcpyAsync(m_ZI8, m_h_z.get(), nz, hipMemcpyHostToDevice, st), "H2D z");
 
     auto index_step = [&](int k) {
         YStepDecIndex d;
@@ -463,25 +297,18 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
         run_priors_from_zhat(st);
         index_step(0);
     });
-    {
-        GraphSlot& slot = m_graphs[kDec1 + 3];
-        if (slot.exec && slot.arg != x_hat) {
-            (void)hipGraphExecDestroy(slot.exec);
-            slot.exec = nullptr;
-        }
-        slot.arg = x_hat;
-    }
+    bind_stage_arg(kDec1 + 3, x_hat);
     int base = 0;
     for (int k = 0; k < 4; ++k) {
         // one GPU -> CPU -> GPU round trip per autoregressive step (dmci_proxy.cpp:857-871)
-        hip_check(hipMemcpyAsync(m_h_totals, m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
+        hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
         hip_check(hipStreamSynchronize(st), "sync");
         const int n = m_h_totals[k];
         if (n > 0) {
-            hip_check(hipMemcpyAsync(m_h_idx, m_CIDX + base, n, hipMemcpyDeviceToHost, st), "D2H indexes");
+            hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX + base, n, hipMemcpyDeviceToHost, st), "D2H indexes");
             hip_check(hipStreamSynchronize(st), "sync");
-            m_dec.decode_y(m_h_idx, n, m_h_dec + base);
-            hip_check(hipMemcpyAsync(m_DECODED + base, m_h_dec + base, n, hipMemcpyHostToDevice, st), "H2D symbols");
+            m_dec.decode_y(m_h_idx.get(), n, m_h_dec.get() + base);
+            hip_check(hipMemcpyAsync(m_DECODED + base, m_h_dec.get() + base, n, hipMemcpyHostToDevice, st), "H2D symbols");
         }
         base += n;
         run_stage(kDec1 + k, st, [&] {

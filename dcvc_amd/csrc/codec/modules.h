@@ -101,20 +101,29 @@ struct Stride2W {
     half_t* w = nullptr;    // [cout][2][2][cin]
     half_t* b = nullptr;
     int cin = 0, cout = 0;
+    bool shortcut = true;   // block-level skip connection (off in the inter models' hyper / prior nets)
     DcbW block;
-    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
-    // x: [H][W][cin] -> tmp, y: [H/2][W/2][cout]
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix, bool shortcut = true);
+    // x: [H][W][cin] -> tmp, y: [H/2][W/2][cout]; without the shortcut tmp may be y
     void forward(View x, View tmp, View y, int H, int W, const half_t* zeros, const Scratch& s,
                  hipStream_t st) const;
 };
 
-// layers.py:162-173: SubpelConv2x(kernel 1, no bias) == 2x2 stride-2 transposed conv
-struct UpsampleW {
-    half_t* w = nullptr;    // [4][cout][cin]
+// layers.py:92-105: SubpelConv2x(kernel 1, no bias) == 2x2 stride-2 transposed conv
+struct SubpelW {
+    half_t* w = nullptr;    // [4 = dy*2+dx][cout][cin]
     int cin = 0, cout = 0;
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);   // prefix + "conv.0.weight"
+    void forward(View x, View y, int H, int W, hipStream_t st) const;               // y: [2H][2W][cout]
+};
+
+// layers.py:162-173: SubpelConv2x + DepthConvBlock
+struct UpsampleW {
+    SubpelW up;
+    bool shortcut = true;
     DcbW block;
-    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
-    // x: [H][W][cin] -> tmp, y: [2H][2W][cout]
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix, bool shortcut = true);
+    // x: [H][W][cin] -> tmp, y: [2H][2W][cout]; without the shortcut tmp may be y
     void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st) const;
 };
 

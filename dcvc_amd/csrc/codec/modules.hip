@@ -208,8 +208,9 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
     }
 }
 
-void Stride2W::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
+void Stride2W::load(const ParamStore& ps, DeviceArena& mem, const std::string& p, bool with_shortcut)
 {
+    shortcut = with_shortcut;
     const HostTensor& wt = ps.at(p + "down.weight");     // [cout][4*cin][1][1], channel = c*4 + dy*2 + dx
     expect_conv(wt, 1, p + "down.weight");
     cout = static_cast<int>(wt.shape[0]);
@@ -232,14 +233,14 @@ void Stride2W::forward(View x, View tmp, View y, int H, int W, const half_t* zer
     d.y = tmp.p; d.ldy = tmp.ld; d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
     d.ksize = 2; d.stride = 2; d.pad = 0;
     conv_kxk(d, st);
-    block.forward(tmp, y, H / 2, W / 2, s, st, /*shortcut=*/true);
+    block.forward(tmp, y, H / 2, W / 2, s, st, shortcut);
 }
 
-void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
+void SubpelW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
 {
-    const HostTensor& wt = ps.at(p + "up.conv.0.weight");   // [4*cout][cin][1][1], row = co*4 + dy*2 + dx
-    expect_conv(wt, 1, p + "up.conv.0.weight");
-    if (ps.has(p + "up.conv.0.bias")) {
+    const HostTensor& wt = ps.at(p + "conv.0.weight");   // [4*cout][cin][1][1], row = co*4 + dy*2 + dx
+    expect_conv(wt, 1, p + "conv.0.weight");
+    if (ps.has(p + "conv.0.bias")) {
         throw std::invalid_argument("biased SubpelConv2x is not a 2x2 transposed conv: " + p);
     }
     cout = static_cast<int>(wt.shape[0]) / 4;
@@ -250,16 +251,27 @@ void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& 
             std::memcpy(&r[(static_cast<size_t>(t) * cout + co) * cin], &wt.h[(static_cast<size_t>(co) * 4 + t) * cin],
                         cin * sizeof(half_t));
     w = mem.upload(r);
+}
+
+void SubpelW::forward(View x, View y, int H, int W, hipStream_t st) const
+{
+    TConv2x2Desc d;
+    d.x = x.p; d.ldx = x.ld; d.w = w; d.y = y.p; d.ldy = y.ld;
+    d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
+    tconv2x2(d, st);
+}
+
+void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p, bool with_shortcut)
+{
+    shortcut = with_shortcut;
+    up.load(ps, mem, p + "up.");
     block.load(ps, mem, p + "conv.");
 }
 
 void UpsampleW::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st) const
 {
-    TConv2x2Desc d;
-    d.x = x.p; d.ldx = x.ld; d.w = w; d.y = tmp.p; d.ldy = tmp.ld;
-    d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
-    tconv2x2(d, st);
-    block.forward(tmp, y, 2 * H, 2 * W, s, st, /*shortcut=*/true);
+    up.forward(x, tmp, H, W, st);
+    block.forward(tmp, y, 2 * H, 2 * W, s, st, shortcut);
 }
 
 }  // namespace dcvc

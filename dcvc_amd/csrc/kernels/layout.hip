@@ -16,7 +16,7 @@ namespace {
 // out[h8][w8][c*64 + dy*8 + dx] = x[min(h8*8+dy, H-1)][min(w8*8+dx, W-1)][c]
 // one thread = one (pixel, c, dy): 8 consecutive dx -> 8 consecutive output channels (16 B store)
 __global__ void pad_unshuffle8_kernel(const half_t* __restrict__ x, int H, int W, int C3,
-                                      half_t* __restrict__ out, int H8, int W8)
+                                      half_t* __restrict__ out, int H8, int W8, int ldout)
 {
     const int per_pix = C3 * 8;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,7 +32,7 @@ __global__ void pad_unshuffle8_kernel(const half_t* __restrict__ x, int H, int W
         const int sw = min(w8 * 8 + dx, W - 1);
         v[dx] = x[(static_cast<size_t>(sh) * W + sw) * C3 + c];
     }
-    *reinterpret_cast<half8*>(out + static_cast<size_t>(pix) * (C3 * 64) + c * 64 + dy * 8) = v;
+    *reinterpret_cast<half8*>(out + static_cast<size_t>(pix) * ldout + c * 64 + dy * 8) = v;
 }
 
 // out[h8*8+dy][w8*8+dx][c] = clamp(in[h8][w8][c*64 + dy*8 + dx])
@@ -127,10 +127,11 @@ inline dim3 grid1d(long long n, int block = 256)
 }  // namespace
 
 void pad_unshuffle8(const half_t* x, int H, int W, int C3, half_t* out, int H8, int W8,
-                    hipStream_t stream)
+                    hipStream_t stream, int ldout)
 {
+    if (ldout == 0) ldout = C3 * 64;
     const long long n = static_cast<long long>(H8) * W8 * C3 * 8;
-    hipLaunchKernelGGL(pad_unshuffle8_kernel, grid1d(n), dim3(256), 0, stream, x, H, W, C3, out, H8, W8);
+    hipLaunchKernelGGL(pad_unshuffle8_kernel, grid1d(n), dim3(256), 0, stream, x, H, W, C3, out, H8, W8, ldout);
     hip_check(hipGetLastError(), "pad_unshuffle8 launch");
 }
 

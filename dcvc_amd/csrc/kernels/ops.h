@@ -77,9 +77,10 @@ void dwconv3x3(const half_t* x, int ldx, const half_t* wt /* [9][C] */, half_t* 
                int H, int W, int C, hipStream_t stream);
 
 // ---------------------------------------------------------------- layout kernels (layout.hip)
-// x: [H][W][C3] (channels_last view of [1, C3, H, W]); out: [H8][W8][C3*64], replicate padding.
+// x: [H][W][C3] (channels_last view of [1, C3, H, W]); out: [H8][W8][C3*64] with pixel stride
+// ldout (0 = dense), replicate padding.
 void pad_unshuffle8(const half_t* x, int H, int W, int C3, half_t* out, int H8, int W8,
-                    hipStream_t stream);
+                    hipStream_t stream, int ldout = 0);
 // in: [H8][W8][C3*64] -> out: [H8*8][W8*8][C3] with optional clamp to [-0.5, 0.5]
 void shuffle8(const half_t* in, int ldin, int H8, int W8, int C3, bool clamp, half_t* out,
               hipStream_t stream);
@@ -152,5 +153,58 @@ struct YStepDecRestore {
     bool first = false;
 };
 void y_step_dec_restore(const YStepDecRestore& d, hipStream_t stream);
+
+// ---------------------------------------------------------------- 2x checkerboard (inter models)
+// mask_0 = first channel half on even (h + w), second half on odd; mask_1 the complement
+// (dmc_ld_proxy.cpp:672-683). A run of 8 channels never straddles the halves, so every 8-channel
+// vector of a pixel belongs to exactly one of the two steps.
+//
+// Encoder, step 0: y *= 1/max(q_dec, 0.5) (in place, all positions; divide_with_clamp,
+//   stream.cu:422-443); mask_0 positions: quantise against the hyper means -> symbol, y_hat;
+//   mask_1 positions: y_hat = 0.
+// Encoder, step 1: mask_1 positions: quantise against the spatial-prior means; then everywhere
+//   y_hat = (y_hat) * max(q_dec, 0.5) (process_with_mask<false,true,true>, stream.cu:549-630),
+//   plus the skip flags / per-block counts of ALL symbols (build_index_enc, stream.cu:130-161).
+struct Y2StepEnc {
+    half_t* y = nullptr; int ldy = 0;
+    const half_t* q_dec = nullptr; int ldq = 0;
+    const half_t* scales = nullptr; int lds = 0;
+    const half_t* means = nullptr; int ldm = 0;
+    half_t* y_hat = nullptr; int ldh = 0;
+    int16_t* sym = nullptr;                 // [P * C] (symbol << 8) + index, NHWC order
+    uint8_t* cond = nullptr;                // [P * C / 8]   (step 1)
+    int32_t* block_count = nullptr;         // [blocks]      (step 1)
+    int H = 0, W = 0, C = 0, step = 0;
+    float skip_thres = 0.f;
+};
+void y2_step_enc(const Y2StepEnc& d, hipStream_t stream);
+
+// Decoder: table index + skip flag of every symbol (build_index_dec, stream.cu:100-128)
+struct Y2DecIndex {
+    const half_t* scales = nullptr; int lds = 0;
+    uint8_t* index = nullptr;
+    uint8_t* cond = nullptr;
+    int32_t* block_count = nullptr;
+    int H = 0, W = 0, C = 0;
+    float skip_thres = 0.f;
+};
+void y2_dec_index(const Y2DecIndex& d, hipStream_t stream);
+
+// Decoder, step 0: scatter the decoded symbols back (conditional_recover, stream.cu:360-383);
+//   mask_0 positions: y_hat = y_q + means; mask_1 positions: y_hat = 0, y_q parked in `yq`.
+// Decoder, step 1: mask_1 positions: y_hat = yq + spatial-prior means; then everywhere
+//   y_hat *= max(q_dec, 0.5)   (restore_y_kernel<true,true>, stream.cu:686-729).
+struct Y2StepDec {
+    const int8_t* decoded = nullptr;        // compacted symbols (step 0)
+    const uint8_t* cond = nullptr;
+    const int32_t* block_count = nullptr;
+    const int32_t* totals = nullptr;
+    int8_t* yq = nullptr;                   // [P * C] scratch
+    const half_t* means = nullptr; int ldm = 0;
+    const half_t* q_dec = nullptr; int ldq = 0;
+    half_t* y_hat = nullptr; int ldh = 0;
+    int H = 0, W = 0, C = 0, step = 0;
+};
+void y2_step_dec(const Y2StepDec& d, hipStream_t stream);
 
 }  // namespace dcvc

@@ -289,6 +289,152 @@ y_step_dec_restore_kernel(const YStepDecRestore d)
     }
 }
 
+// ----------------------------------------------------------------- 2x checkerboard (inter models)
+__device__ __forceinline__ bool active_2x(int step, int h, int w, int ch, int half_c)
+{
+    const bool even = ((h ^ w) & 1) == 0;
+    const bool first = ch < half_c;
+    return ((even == first) ? 0 : 1) == step;
+}
+
+__device__ __forceinline__ half_t clamp_min_half(half_t q)
+{
+    return static_cast<float>(q) > 0.5f ? q : static_cast<half_t>(0.5f);     // max(q, 0.5); NaN -> 0.5
+}
+
+__global__ void __launch_bounds__(kBlockThreads)
+y2_step_enc_kernel(const Y2StepEnc d, const LutView lutv, const half_t thres)
+{
+    __shared__ int lds[4];
+    const int total = d.H * d.W * d.C;
+    const int e0 = (blockIdx.x * kBlockThreads + threadIdx.x) * kElemsPerThread;
+    int kept = 0;
+    if (e0 < total) {
+        const int pix = e0 / d.C;
+        const int ch = e0 - pix * d.C;
+        const int h = pix / d.W, w = pix - h * d.W;
+        const bool active = active_2x(d.step, h, w, ch, d.C >> 1);
+        half_t* yp = d.y + static_cast<size_t>(pix) * d.ldy + ch;
+        half_t* yhp = d.y_hat + static_cast<size_t>(pix) * d.ldh + ch;
+        const half8 q8 = *reinterpret_cast<const half8*>(d.q_dec + static_cast<size_t>(pix) * d.ldq + ch);
+        const half8 s8 = *reinterpret_cast<const half8*>(d.scales + static_cast<size_t>(pix) * d.lds + ch);
+        half8 y8 = *reinterpret_cast<const half8*>(yp);
+        if (d.step == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const half_t r = to_half(1.0f / static_cast<float>(clamp_min_half(q8[i])));
+                y8[i] = hmul(y8[i], r);
+            }
+            *reinterpret_cast<half8*>(yp) = y8;
+        }
+        half8 yh = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        unsigned flags = 0;
+        if (active) {
+            const half8 m8 = *reinterpret_cast<const half8*>(d.means + static_cast<size_t>(pix) * d.ldm + ch);
+            typedef short short8 __attribute__((ext_vector_type(8)));
+            short8 s_out;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const half_t y_res = hsub(y8[i], m8[i]);
+                float q = round_half_away(static_cast<float>(y_res));
+                const bool keep = static_cast<float>(s8[i]) > static_cast<float>(thres);
+                q = keep ? q : 0.f;
+                q = fmaxf(fminf(q, 127.f), -128.f);
+                yh[i] = to_half(q + static_cast<float>(m8[i]));
+                s_out[i] = static_cast<short>(static_cast<int>(q) * 256 + scale_to_index(s8[i], lutv));
+            }
+            *reinterpret_cast<short8*>(d.sym + e0) = s_out;
+        } else if (d.step == 1) {
+            yh = *reinterpret_cast<const half8*>(yhp);
+        }
+        if (d.step == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                yh[i] = hmul(yh[i], clamp_min_half(q8[i]));
+                flags |= (static_cast<float>(s8[i]) > static_cast<float>(thres) ? 1u : 0u) << i;
+            }
+            d.cond[e0 >> 3] = static_cast<uint8_t>(flags);
+            kept = __popc(flags);
+        }
+        *reinterpret_cast<half8*>(yhp) = yh;
+    }
+    if (d.step == 1) {
+        const int s = block_sum_256(kept, lds);
+        if (threadIdx.x == 0) d.block_count[blockIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kBlockThreads)
+y2_dec_index_kernel(const Y2DecIndex d, const LutView lutv, const half_t thres)
+{
+    __shared__ int lds[4];
+    const int total = d.H * d.W * d.C;
+    const int e0 = (blockIdx.x * kBlockThreads + threadIdx.x) * kElemsPerThread;
+    int kept = 0;
+    if (e0 < total) {
+        const int pix = e0 / d.C;
+        const int ch = e0 - pix * d.C;
+        const half8 s8 = *reinterpret_cast<const half8*>(d.scales + static_cast<size_t>(pix) * d.lds + ch);
+        unsigned flags = 0;
+        typedef unsigned char uchar8 __attribute__((ext_vector_type(8)));
+        uchar8 idx8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            idx8[i] = static_cast<unsigned char>(scale_to_index(s8[i], lutv));
+            flags |= (static_cast<float>(s8[i]) > static_cast<float>(thres) ? 1u : 0u) << i;
+        }
+        *reinterpret_cast<uchar8*>(d.index + e0) = idx8;
+        d.cond[e0 >> 3] = static_cast<uint8_t>(flags);
+        kept = __popc(flags);
+    }
+    const int s = block_sum_256(kept, lds);
+    if (threadIdx.x == 0) d.block_count[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(kBlockThreads)
+y2_step_dec_kernel(const Y2StepDec d)
+{
+    __shared__ int lds[4];
+    const int total = d.H * d.W * d.C;
+    const int e0 = (blockIdx.x * kBlockThreads + threadIdx.x) * kElemsPerThread;
+    typedef signed char char8 __attribute__((ext_vector_type(8)));
+    char8 q8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (d.step == 0) {
+        unsigned flags = 0;
+        if (e0 < total) flags = d.cond[e0 >> 3];
+        int step_base;
+        int pos = block_base_and_rank(d.block_count, d.totals, 0, __popc(flags), lds, step_base);
+        if (e0 >= total) return;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (flags & (1u << i)) q8[i] = d.decoded[pos++];
+        }
+    }
+    if (e0 >= total) return;
+    const int pix = e0 / d.C;
+    const int ch = e0 - pix * d.C;
+    const int h = pix / d.W, w = pix - h * d.W;
+    const bool active = active_2x(d.step, h, w, ch, d.C >> 1);
+    half_t* yhp = d.y_hat + static_cast<size_t>(pix) * d.ldh + ch;
+    half8 yh = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (active) {
+        if (d.step == 1) q8 = *reinterpret_cast<const char8*>(d.yq + e0);
+        const half8 m8 = *reinterpret_cast<const half8*>(d.means + static_cast<size_t>(pix) * d.ldm + ch);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yh[i] = to_half(static_cast<float>(q8[i]) + static_cast<float>(m8[i]));
+    } else if (d.step == 0) {
+        *reinterpret_cast<char8*>(d.yq + e0) = q8;
+    } else {
+        yh = *reinterpret_cast<const half8*>(yhp);
+    }
+    if (d.step == 1) {
+        const half8 qd = *reinterpret_cast<const half8*>(d.q_dec + static_cast<size_t>(pix) * d.ldq + ch);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yh[i] = hmul(yh[i], clamp_min_half(qd[i]));
+    }
+    *reinterpret_cast<half8*>(yhp) = yh;
+}
+
 // ----------------------------------------------------------------- z
 __global__ void round_z_kernel(const half_t* __restrict__ z, half_t* __restrict__ z_hat,
                                int8_t* __restrict__ z_i8, int count)
@@ -374,6 +520,32 @@ void y_step_dec_restore(const YStepDecRestore& d, hipStream_t stream)
     hipLaunchKernelGGL(y_step_dec_restore_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0,
                        stream, d);
     hip_check(hipGetLastError(), "y_step_dec_restore launch");
+}
+
+void y2_step_enc(const Y2StepEnc& d, hipStream_t stream)
+{
+    if (d.C % 16 != 0 || (d.step != 0 && d.step != 1)) throw std::invalid_argument("y2_step_enc: bad C / step");
+    const int count = d.H * d.W * d.C;
+    hipLaunchKernelGGL(y2_step_enc_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d,
+                       lut_view(), static_cast<half_t>(d.skip_thres));
+    hip_check(hipGetLastError(), "y2_step_enc launch");
+}
+
+void y2_dec_index(const Y2DecIndex& d, hipStream_t stream)
+{
+    if (d.C % 16 != 0) throw std::invalid_argument("y2_dec_index: C must be a multiple of 16");
+    const int count = d.H * d.W * d.C;
+    hipLaunchKernelGGL(y2_dec_index_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d,
+                       lut_view(), static_cast<half_t>(d.skip_thres));
+    hip_check(hipGetLastError(), "y2_dec_index launch");
+}
+
+void y2_step_dec(const Y2StepDec& d, hipStream_t stream)
+{
+    if (d.C % 16 != 0 || (d.step != 0 && d.step != 1)) throw std::invalid_argument("y2_step_dec: bad C / step");
+    const int count = d.H * d.W * d.C;
+    hipLaunchKernelGGL(y2_step_dec_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d);
+    hip_check(hipGetLastError(), "y2_step_dec launch");
 }
 
 void round_z(const half_t* z, half_t* z_hat, int8_t* z_i8, int count, hipStream_t stream)

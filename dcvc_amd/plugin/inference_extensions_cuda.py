@@ -29,6 +29,21 @@ _F = dict(
     debug_read=_lib.fn("dcvc_dmci_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
 )
 
+_SET_PARAM_ARGS = [_vp, _ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_vp), ctypes.POINTER(_ci),
+                   ctypes.POINTER(_ci), ctypes.POINTER(ctypes.c_int64), ctypes.c_float]
+_LD = dict(
+    create=_lib.fn("dcvc_dmcld_create", _vp, []),
+    destroy=_lib.fn("dcvc_dmcld_destroy", None, [_vp]),
+    set_param=_lib.fn("dcvc_dmcld_set_param", _ci, _SET_PARAM_ARGS),
+    add_ref=_lib.fn("dcvc_dmcld_add_ref_feature_from_frame", _ci, [_vp, _vp, _ci, _ci, _ci, _vp]),
+    compress=_lib.fn("dcvc_dmcld_compress", _ci, [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
+    get_stream=_lib.fn("dcvc_dmcld_get_stream", ctypes.c_int64, [_vp, _vp, ctypes.c_size_t]),
+    decompress=_lib.fn("dcvc_dmcld_decompress", _ci,
+                       [_vp, _vp, ctypes.c_size_t, _ci, _ci, _ci, _ci, _ci, _vp, _vp]),
+    use_graphs=_lib.fn("dcvc_dmcld_set_use_graphs", _ci, [_vp, _ci]),
+    debug_read=_lib.fn("dcvc_dmcld_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
+)
+
 _DTYPES = {torch.float16: 0, torch.float32: 1, torch.int32: 2}
 
 
@@ -69,24 +84,42 @@ def _nhwc_ptr(x, channels):
     return x, ctypes.c_void_p(x.data_ptr())
 
 
-class DMCIProxy:
-    """bind.cpp:12-16 / dmci_proxy.h:134-150."""
+class _Proxy:
+    """Handle ownership + the calls every proxy class has."""
+    _FN = None
 
     def __init__(self):
-        self._h = _F["create"]()
+        self._h = self._FN["create"]()
         if not self._h:
             raise _lib.DcvcError(_lib.lib().dcvc_last_error().decode())
         self._x_hat = None
+        self._destroy = self._FN["destroy"]          # survives module teardown at interpreter exit
 
-    def __del__(self, _destroy=_F["destroy"]):
+    def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _destroy(h)
+            self._destroy(h)
 
     def set_param(self, state_dict, skip_thres):
         n, names, ptrs, dtypes, ndims, dims, keep = _pack_state_dict(state_dict)
-        _lib.check(_F["set_param"](self._h, n, names, ptrs, dtypes, ndims, dims, float(skip_thres)))
+        _lib.check(self._FN["set_param"](self._h, n, names, ptrs, dtypes, ndims, dims, float(skip_thres)))
         del keep
+
+    def _stream_bytes(self):
+        n = self._FN["get_stream"](self._h, None, 0)
+        out = np.empty(n, dtype=np.uint8)
+        self._FN["get_stream"](self._h, out.ctypes.data_as(_vp), n)
+        return out
+
+    # ---- not part of the reference surface
+    def set_use_graphs(self, on):
+        _lib.check(self._FN["use_graphs"](self._h, 1 if on else 0))
+
+    def debug_read(self, name, dtype):
+        n = _lib.check(self._FN["debug_read"](self._h, name.encode(), None, 0, _stream_ptr()))
+        buf = np.empty(n, dtype=np.uint8)
+        _lib.check(self._FN["debug_read"](self._h, name.encode(), buf.ctypes.data_as(_vp), n, _stream_ptr()))
+        return buf.view(dtype)
 
     def _out_buffer(self, height, width, device):
         h16, w16 = (height + 15) // 16 * 16, (width + 15) // 16 * 16
@@ -96,6 +129,12 @@ class DMCIProxy:
                 memory_format=torch.channels_last)
         return self._x_hat
 
+
+
+class DMCIProxy(_Proxy):
+    """bind.cpp:12-16 / dmci_proxy.h:134-150."""
+    _FN = _F
+
     def compress(self, x, qp, padding_b, padding_r):
         """-> (np.ndarray[uint8] bit stream, x_hat [1, 3, ceil16(H), ceil16(W)], ec_parallel)"""
         x, xp = _nhwc_ptr(x, 3)
@@ -103,10 +142,7 @@ class DMCIProxy:
         x_hat = self._out_buffer(height, width, x.device)
         ec = _lib.check(_F["compress"](self._h, xp, height, width, int(qp), int(padding_b), int(padding_r),
                                        ctypes.c_void_p(x_hat.data_ptr()), _stream_ptr()))
-        n = _F["get_stream"](self._h, None, 0)
-        out = np.empty(n, dtype=np.uint8)
-        _F["get_stream"](self._h, out.ctypes.data_as(_vp), n)
-        return out, x_hat, int(ec)
+        return self._stream_bytes(), x_hat, int(ec)
 
     def decompress(self, bit_stream, qp, height, width, entropy_coder_parallel):
         bs = np.ascontiguousarray(bit_stream, dtype=np.uint8)
@@ -117,12 +153,30 @@ class DMCIProxy:
                                     _stream_ptr()))
         return x_hat
 
-    # ---- not part of the reference surface
-    def set_use_graphs(self, on):
-        _lib.check(_F["use_graphs"](self._h, 1 if on else 0))
 
-    def debug_read(self, name, dtype):
-        n = _lib.check(_F["debug_read"](self._h, name.encode(), None, 0, _stream_ptr()))
-        buf = np.empty(n, dtype=np.uint8)
-        _lib.check(_F["debug_read"](self._h, name.encode(), buf.ctypes.data_as(_vp), n, _stream_ptr()))
-        return buf.view(dtype)
+class DMCLDProxy(_Proxy):
+    """bind.cpp:31-38 / dmc_ld_proxy.h: the low-delay inter codec."""
+    _FN = _LD
+
+    def add_ref_feature_from_frame(self, frame, apply_feature_adaptor=True):
+        frame, fp = _nhwc_ptr(frame, 3)
+        _lib.check(_LD["add_ref"](self._h, fp, int(frame.shape[2]), int(frame.shape[3]),
+                                  1 if apply_feature_adaptor else 0, _stream_ptr()))
+
+    def compress(self, x, qp, reset_feature_memory, padding_b, padding_r):
+        """-> (np.ndarray[uint8] bit stream, ec_parallel)"""
+        x, xp = _nhwc_ptr(x, 3)
+        ec = _lib.check(_LD["compress"](self._h, xp, int(x.shape[2]), int(x.shape[3]), int(qp),
+                                        1 if reset_feature_memory else 0, int(padding_b), int(padding_r),
+                                        _stream_ptr()))
+        return self._stream_bytes(), int(ec)
+
+    def decompress(self, bit_stream, qp, height, width, entropy_coder_parallel, reset_feature_memory):
+        bs = np.ascontiguousarray(bit_stream, dtype=np.uint8)
+        device = torch.device("cuda", torch.cuda.current_device())
+        x_hat = self._out_buffer(int(height), int(width), device)
+        _lib.check(_LD["decompress"](self._h, bs.ctypes.data_as(_vp), bs.size, int(qp), int(height),
+                                     int(width), int(entropy_coder_parallel),
+                                     1 if reset_feature_memory else 0,
+                                     ctypes.c_void_p(x_hat.data_ptr()), _stream_ptr()))
+        return x_hat

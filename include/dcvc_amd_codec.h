@@ -60,6 +60,43 @@ int dcvc_dmci_set_use_graphs(dcvc_dmci* c, int on);
  * "unshuffled", "features", "totals", "symbols") to host memory; returns its size in bytes. */
 int64_t dcvc_dmci_debug_read(dcvc_dmci* c, const char* name, void* dst, size_t cap, void* stream);
 
+/* ------------------------------------------------------------------ DMCLDProxy (low-delay inter)
+ * bind.cpp:31-38 / dmc_ld_proxy.h. One picture per call; the temporal state (feature memory,
+ * last decoded feature, context, temporal prior) stays on the device inside the object. */
+typedef struct dcvc_dmcld dcvc_dmcld;
+
+dcvc_dmcld* dcvc_dmcld_create(void);
+void dcvc_dmcld_destroy(dcvc_dmcld* c);
+
+/* DMCLDProxy.set_param(state_dict, skip_thres), dmc_ld_proxy.cpp:595-639; arguments as for
+ * dcvc_dmci_set_param. Clears the temporal state. */
+int dcvc_dmcld_set_param(dcvc_dmcld* c, int n, const char* const* names, const void* const* data,
+                         const int* dtypes, const int* ndims, const int64_t* dims, float skip_thres);
+
+/* DMCLDProxy.add_ref_feature_from_frame(frame, apply_feature_adaptor), dmc_ld_proxy.cpp:407-418.
+ * frame: device fp16 [height][width][3], the intra codec's reconstruction. apply_adaptor != 0 is
+ * the encoder's call (memory, context and temporal prior are derived immediately), 0 the
+ * decoder's (they are derived by the next decompress). */
+int dcvc_dmcld_add_ref_feature_from_frame(dcvc_dmcld* c, const void* frame, int height, int width,
+                                          int apply_adaptor, void* stream);
+
+/* DMCLDProxy.compress(x, qp, reset_feature_memory, padding_b, padding_r) -> (bit_stream,
+ * ec_parallel), dmc_ld_proxy.cpp:420-473. Returns ec_parallel; bytes via dcvc_dmcld_get_stream. */
+int dcvc_dmcld_compress(dcvc_dmcld* c, const void* x, int height, int width, int qp,
+                        int reset_feature_memory, int padding_b, int padding_r, void* stream);
+int64_t dcvc_dmcld_get_stream(dcvc_dmcld* c, uint8_t* dst, size_t cap);
+
+/* DMCLDProxy.decompress(bit_stream, qp, height, width, ec_parallel, reset_feature_memory) ->
+ * x_hat, dmc_ld_proxy.cpp:475-593. x_hat: device fp16 [ceil16(height)][ceil16(width)][3]. */
+int dcvc_dmcld_decompress(dcvc_dmcld* c, const uint8_t* bit_stream, size_t nbytes, int qp, int height,
+                          int width, int ec_parallel, int reset_feature_memory, void* x_hat,
+                          void* stream);
+
+int dcvc_dmcld_set_use_graphs(dcvc_dmcld* c, int on);
+/* Test hook ("y", "y_hat", "common", "means1", "z_i8", "memory", "feature_p", "ctx", "temporal",
+ * "feature_i", "symbols", "totals"); dense copy, returns the size in bytes. */
+int64_t dcvc_dmcld_debug_read(dcvc_dmcld* c, const char* name, void* dst, size_t cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
