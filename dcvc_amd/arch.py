@@ -152,3 +152,66 @@ def dmc_ld_spec():
     s["q_decoder"] = (QP_NUM, d)
     s["q_feature"] = (QP_NUM, 2 * y)
     return s
+
+
+# ---------------------------------------------------------------------------------------- DMC HT-S / HT-L
+# /root/reference/src/models/video_model_ht.py:16-23
+HT_FRAME_DELAY = 8
+HT_CH_SRC_INTRA = 192
+HT_CH_SRC = HT_CH_SRC_INTRA * HT_FRAME_DELAY
+HT_CH_Y, HT_CH_Z, HT_CH_D, HT_CH_M, HT_CH_RECON = 256, 128, 512, 512, 256
+
+
+def dmc_ht_spec(is_hts=True):
+    """Hierarchical inter models, 8 pictures per call (video_model_ht.py:26-355). HT-S uses the
+    half-width blocks (dcb2) in the picture-resolution networks, HT-L full-width ones and deeper
+    chains, a 3x3 biased sub-pixel upsampler in the decoder and scales from the spatial prior."""
+    s = OrderedDict()
+    bit_estimator(s, "bit_estimator_z.", HT_CH_Z)
+    y, z, d, m, r = HT_CH_Y, HT_CH_Z, HT_CH_D, HT_CH_M, HT_CH_RECON
+    half = is_hts
+
+    def chain(prefix, cin, c, n, dcb2):
+        depth_conv_block(s, prefix + "0.", cin, c, dcb2=dcb2)
+        for i in range(1, n):
+            depth_conv_block(s, prefix + "%d." % i, c, c, dcb2=dcb2)
+
+    chain("feature_adaptor_i.conv.", HT_CH_SRC_INTRA, m, 4 if is_hts else 3, half)     # :95-114
+    chain("feature_adaptor_m.conv.", m + d, m, 6 if is_hts else 10, half)              # :117-146
+    chain("feature_extractor.conv.", m, d, 5 if is_hts else 2, half)                   # :149-166
+    chain("encoder.conv1.", HT_CH_SRC + d, d, 6 if is_hts else 7, half)                # :63-92
+    _conv(s, "encoder.down", d, y, k=3)
+    depth_conv_block(s, "hyper_encoder.conv.0.", y, y)                                 # :186-201
+    residual_block_stride2(s, "hyper_encoder.conv.1.", y, y)
+    residual_block_stride2(s, "hyper_encoder.conv.2.", y, z)
+    for i, (cin, cout) in enumerate(((z, y), (y, y))):                                 # :169-183
+        _conv(s, "hyper_decoder.conv.%d.up.conv.0" % i, cin, cout * 4, bias=not is_hts)
+        depth_conv_block(s, "hyper_decoder.conv.%d.conv." % i, cout, cout)
+    depth_conv_block(s, "hyper_decoder.conv.2.", y, y)
+    residual_block_stride2(s, "temporal_prior_encoder.conv.", d, 2 * y)                # :305-316
+    chain("y_prior_fusion.conv.", 3 * y, 3 * y, 3, False)                              # :204-215
+    _conv(s, "y_prior_fusion.conv.3", 3 * y, 3 * y)
+    _conv(s, "y_spatial_prior_reduction", 3 * y, y)                                    # :337-344
+    for i in (1, 2, 3):
+        depth_conv_block(s, "y_spatial_prior_adaptor_%d." % i, 2 * y, 2 * y, force_adaptor=True)
+    chain("y_spatial_prior.conv.", 2 * y, 2 * y, 3, False)                             # :278-290
+    _conv(s, "y_spatial_prior.conv.3", 2 * y, y if is_hts else 2 * y)
+    if is_hts:                                                                         # :26-60
+        _conv(s, "decoder.up.conv.0", y, 4 * d, bias=False)
+    else:
+        _conv(s, "decoder.up.conv.0", y, 4 * d, k=3)
+    chain("decoder.conv1.", 2 * d, d, 7 if is_hts else 11, half)
+    if is_hts:                                                                         # :218-275
+        for i in range(HT_FRAME_DELAY // 2):
+            depth_conv_block(s, "recon_head.conv1.%d.0." % i, d, d)
+        for i in range(HT_FRAME_DELAY):
+            chain("recon_head.conv2.%d." % i, d, r, 3, False)
+            _conv(s, "recon_head.conv2.%d.3" % i, r, HT_CH_SRC_INTRA)
+    else:
+        for i in range(HT_FRAME_DELAY):
+            chain("recon_head.conv.%d." % i, d, r, 5, False)
+            _conv(s, "recon_head.conv.%d.5" % i, r, HT_CH_SRC_INTRA)
+    s["q_encoder"] = (QP_NUM, d)                                                       # :349-351
+    s["q_decoder"] = (QP_NUM, d)
+    s["q_feature"] = (QP_NUM, d)
+    return s

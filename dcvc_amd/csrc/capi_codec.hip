@@ -1,5 +1,6 @@
 // C ABI of the picture codecs (include/dcvc_amd_codec.h).
 #include "capi_common.h"
+#include "codec/dmc_ht.h"
 #include "codec/dmc_ld.h"
 #include "codec/dmci.h"
 #include "dcvc_amd_codec.h"
@@ -12,6 +13,11 @@ struct dcvc_dmci {
 
 struct dcvc_dmcld {
     dcvc::DmcLdCodec codec;
+};
+
+struct dcvc_dmcht {
+    explicit dcvc_dmcht(bool is_hts) : codec(is_hts) {}
+    dcvc::DmcHtCodec codec;
 };
 
 namespace {
@@ -167,6 +173,79 @@ int dcvc_dmcld_set_use_graphs(dcvc_dmcld* c, int on)
 }
 
 int64_t dcvc_dmcld_debug_read(dcvc_dmcld* c, const char* name, void* dst, size_t cap, void* stream)
+{
+    int64_t n = -1;
+    const int rc = dcvc::guarded([&] {
+        n = static_cast<int64_t>(c->codec.debug_read(name, dst, cap, static_cast<hipStream_t>(stream)));
+    });
+    return rc < 0 ? rc : n;
+}
+
+// ------------------------------------------------------------------------------------ DMC-HT
+dcvc_dmcht* dcvc_dmcht_create(int is_hts)
+{
+    dcvc_dmcht* c = nullptr;
+    dcvc::guarded([&] { c = new dcvc_dmcht(is_hts != 0); });
+    return c;
+}
+
+void dcvc_dmcht_destroy(dcvc_dmcht* c)
+{
+    delete c;
+}
+
+int dcvc_dmcht_set_param(dcvc_dmcht* c, int n, const char* const* names, const void* const* data,
+                         const int* dtypes, const int* ndims, const int64_t* dims, float skip_thres)
+{
+    return dcvc::guarded([&] {
+        c->codec.set_param(make_store(n, names, data, dtypes, ndims, dims), skip_thres);
+    });
+}
+
+int dcvc_dmcht_add_ref_feature_from_frame(dcvc_dmcht* c, const void* frame, int height, int width,
+                                          int apply_adaptor, void* stream)
+{
+    return dcvc::guarded([&] {
+        c->codec.add_ref_feature_from_frame(static_cast<const dcvc::half_t*>(frame), height, width,
+                                            apply_adaptor != 0, static_cast<hipStream_t>(stream));
+    });
+}
+
+int dcvc_dmcht_compress(dcvc_dmcht* c, const void* x, int height, int width, int qp,
+                        int reset_feature_memory, int padding_b, int padding_r, void* stream)
+{
+    int ec = -1;
+    const int rc = dcvc::guarded([&] {
+        check_padding16(height, width, padding_b, padding_r);
+        ec = c->codec.compress(static_cast<const dcvc::half_t*>(x), height, width, qp,
+                               reset_feature_memory != 0, static_cast<hipStream_t>(stream));
+    });
+    return rc < 0 ? rc : ec;
+}
+
+int64_t dcvc_dmcht_get_stream(dcvc_dmcht* c, uint8_t* dst, size_t cap)
+{
+    const auto& s = c->codec.stream_bytes();
+    if (dst != nullptr) std::memcpy(dst, s.data(), s.size() < cap ? s.size() : cap);
+    return static_cast<int64_t>(s.size());
+}
+
+int dcvc_dmcht_decompress(dcvc_dmcht* c, const uint8_t* bit_stream, size_t nbytes, int qp, int height,
+                          int width, int ec_parallel, int reset_feature_memory, void* x_hat,
+                          void* stream)
+{
+    return dcvc::guarded([&] {
+        c->codec.decompress(bit_stream, nbytes, qp, height, width, ec_parallel, reset_feature_memory != 0,
+                            static_cast<dcvc::half_t*>(x_hat), static_cast<hipStream_t>(stream));
+    });
+}
+
+int dcvc_dmcht_set_use_graphs(dcvc_dmcht* c, int on)
+{
+    return dcvc::guarded([&] { c->codec.set_use_graphs(on != 0); });
+}
+
+int64_t dcvc_dmcht_debug_read(dcvc_dmcht* c, const char* name, void* dst, size_t cap, void* stream)
 {
     int64_t n = -1;
     const int rc = dcvc::guarded([&] {

@@ -290,7 +290,7 @@ int DmcLdCodec::compress(const half_t* x, int height, int width, int qp, bool re
         run_encoder(st);
         run_hyper_encoder(st);
         run_priors(st);
-        Y2StepEnc d;
+        MaskStepEnc d;
         d.y = m_Y; d.ldy = kChY;
         d.q_dec = m_CATSP + kChY; d.ldq = 4 * kChY;
         d.scales = m_CATSP + 2 * kChY; d.lds = 4 * kChY;
@@ -298,10 +298,10 @@ int DmcLdCodec::compress(const half_t* x, int height, int width, int qp, bool re
         d.y_hat = m_CATSP; d.ldh = 4 * kChY;
         d.sym = m_SYM; d.cond = m_COND; d.block_count = m_CNT;
         d.H = g.H16; d.W = g.W16; d.C = kChY; d.step = 0; d.skip_thres = m_skip_thres;
-        y2_step_enc(d, st);
+        mask_step_enc(d, st);
         run_spatial_prior(st);
         d.means = m_MEANS1; d.ldm = kChY; d.step = 1;
-        y2_step_enc(d, st);
+        mask_step_enc(d, st);
         compact(m_SYM, 2, m_COND, m_CNT, g.P16() * kChY, m_COMP, m_TOTALS, 0, st);
     });
     submit(st, [this, qp] { entropy_encode(qp); });
@@ -372,11 +372,11 @@ void DmcLdCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
     run_stage(kDec1, st, [&] {
         int8_to_half(m_ZI8, m_ZH, nz, st);
         run_priors(st);
-        Y2DecIndex d;
+        MaskDecIndex d;
         d.scales = m_CATSP + 2 * kChY; d.lds = 4 * kChY;
         d.index = m_IDX; d.cond = m_COND; d.block_count = m_CNT;
         d.H = g.H16; d.W = g.W16; d.C = kChY; d.skip_thres = m_skip_thres;
-        y2_dec_index(d, st);
+        mask_dec_index(d, st);
         compact(m_IDX, 1, m_COND, m_CNT, ny, m_CIDX, m_TOTALS, 0, st);
     });
     hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
@@ -395,16 +395,16 @@ void DmcLdCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
     }
     bind_stage_arg(kDec3, x_hat);
     run_stage(kDec3, st, [&] {
-        Y2StepDec d;
+        MaskStepDec d;
         d.decoded = m_DECODED; d.cond = m_COND; d.block_count = m_CNT; d.totals = m_TOTALS; d.yq = m_YQ;
         d.means = m_CATSP + 3 * kChY; d.ldm = 4 * kChY;
         d.q_dec = m_CATSP + kChY; d.ldq = 4 * kChY;
         d.y_hat = m_CATSP; d.ldh = 4 * kChY;
         d.H = g.H16; d.W = g.W16; d.C = kChY; d.step = 0;
-        y2_step_dec(d, st);
+        mask_step_dec(d, st);
         run_spatial_prior(st);
         d.means = m_MEANS1; d.ldm = kChY; d.step = 1;
-        y2_step_dec(d, st);
+        mask_step_dec(d, st);
         run_decoder(st);
         run_recon_head(x_hat, st);
     });

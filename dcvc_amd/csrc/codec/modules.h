@@ -109,12 +109,18 @@ struct Stride2W {
                  hipStream_t st) const;
 };
 
-// layers.py:92-105: SubpelConv2x(kernel 1, no bias) == 2x2 stride-2 transposed conv
+// layers.py:92-105 SubpelConv2x / layers_proxy.cpp:269-324. Without a bias (kernel 1) it is a
+// 2x2 stride-2 transposed conv; with a bias (HT-L: kernel 1 or 3) a k x k conv + bias rounded to
+// fp16 followed by pixel_shuffle(2), which needs a [H][W][4*cout] temporary.
 struct SubpelW {
-    half_t* w = nullptr;    // [4 = dy*2+dx][cout][cin]
-    int cin = 0, cout = 0;
+    half_t* w = nullptr;    // no bias: [4 = dy*2+dx][cout][cin]; biased: [4*cout][k][k][cin]
+    half_t* b = nullptr;    // [4*cout] or null
+    int cin = 0, cout = 0, k = 1;
     void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);   // prefix + "conv.0.weight"
-    void forward(View x, View y, int H, int W, hipStream_t st) const;               // y: [2H][2W][cout]
+    size_t tmp_elems(int H, int W) const { return b ? static_cast<size_t>(H) * W * 4 * cout : 0; }
+    // y: [2H][2W][cout]
+    void forward(View x, View y, int H, int W, hipStream_t st, half_t* tmp = nullptr,
+                 const half_t* zeros = nullptr) const;
 };
 
 // layers.py:162-173: SubpelConv2x + DepthConvBlock
@@ -123,8 +129,21 @@ struct UpsampleW {
     bool shortcut = true;
     DcbW block;
     void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix, bool shortcut = true);
-    // x: [H][W][cin] -> tmp, y: [2H][2W][cout]; without the shortcut tmp may be y
-    void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st) const;
+    // x: [H][W][cin] -> tmp, y: [2H][2W][cout]; without the shortcut tmp may be y.
+    // up_tmp / zeros: only for a biased upsampler (SubpelW::tmp_elems)
+    void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
+                 half_t* up_tmp = nullptr, const half_t* zeros = nullptr) const;
+};
+
+// nn.Sequential of DepthConvBlocks prefix + "0.", "1.", ... (as many as the checkpoint has)
+struct DcbChain {
+    std::vector<DcbW> blocks;
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
+    // x -> (first block) -> tmp -> ... in place ... -> (last block) -> y; q_fused_last: scale fused
+    // into the last block (DepthConvBlockProxy::forward(x, quant), layers_proxy.cpp:92-95)
+    void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
+                 const half_t* q_fused_last = nullptr) const;
+    size_t size() const { return blocks.size(); }
 };
 
 // dense k x k conv weight in tap-major layout

@@ -238,13 +238,22 @@ void Stride2W::forward(View x, View tmp, View y, int H, int W, const half_t* zer
 
 void SubpelW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
 {
-    const HostTensor& wt = ps.at(p + "conv.0.weight");   // [4*cout][cin][1][1], row = co*4 + dy*2 + dx
-    expect_conv(wt, 1, p + "conv.0.weight");
-    if (ps.has(p + "conv.0.bias")) {
-        throw std::invalid_argument("biased SubpelConv2x is not a 2x2 transposed conv: " + p);
+    const HostTensor& wt = ps.at(p + "conv.0.weight");   // [4*cout][cin][k][k], row = co*4 + dy*2 + dx
+    if (wt.shape.size() != 4 || wt.shape[2] != wt.shape[3]) {
+        throw std::invalid_argument("unexpected weight shape for " + p + "conv.0.weight");
     }
     cout = static_cast<int>(wt.shape[0]) / 4;
     cin = static_cast<int>(wt.shape[1]);
+    k = static_cast<int>(wt.shape[2]);
+    if (ps.has(p + "conv.0.bias")) {
+        ConvKW c;
+        c.load(ps, mem, p + "conv.0.");
+        w = c.w;
+        b = c.b;
+        return;
+    }
+    if (k != 1) throw std::invalid_argument("SubpelConv2x without bias must have kernel 1: " + p);
+    b = nullptr;
     std::vector<half_t> r(wt.h.size());
     for (int co = 0; co < cout; ++co)
         for (int t = 0; t < 4; ++t)
@@ -253,12 +262,29 @@ void SubpelW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
     w = mem.upload(r);
 }
 
-void SubpelW::forward(View x, View y, int H, int W, hipStream_t st) const
+void SubpelW::forward(View x, View y, int H, int W, hipStream_t st, half_t* tmp, const half_t* zeros) const
 {
-    TConv2x2Desc d;
-    d.x = x.p; d.ldx = x.ld; d.w = w; d.y = y.p; d.ldy = y.ld;
-    d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
-    tconv2x2(d, st);
+    if (b == nullptr) {
+        TConv2x2Desc d;
+        d.x = x.p; d.ldx = x.ld; d.w = w; d.y = y.p; d.ldy = y.ld;
+        d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
+        tconv2x2(d, st);
+        return;
+    }
+    if (tmp == nullptr) throw std::invalid_argument("biased SubpelConv2x needs a temporary");
+    if (k == 1) {
+        Conv1x1Desc d;
+        d.x = x.p; d.ldx = x.ld; d.w = w; d.bias = b; d.y = tmp; d.ldy = 4 * cout;
+        d.pixels = H * W; d.cin = cin; d.cout = 4 * cout;
+        conv1x1(d, st);
+    } else {
+        ConvKxKDesc d;
+        d.x = x.p; d.ldx = x.ld; d.w = w; d.bias = b; d.zeros = zeros;
+        d.y = tmp; d.ldy = 4 * cout; d.in_h = H; d.in_w = W; d.cin = cin; d.cout = 4 * cout;
+        d.ksize = k; d.stride = 1; d.pad = k / 2;
+        conv_kxk(d, st);
+    }
+    shuffle2(tmp, 4 * cout, H, W, cout, y.p, y.ld, st);
 }
 
 void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p, bool with_shortcut)
@@ -268,10 +294,33 @@ void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& 
     block.load(ps, mem, p + "conv.");
 }
 
-void UpsampleW::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st) const
+void UpsampleW::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
+                        half_t* up_tmp, const half_t* zeros) const
 {
-    up.forward(x, tmp, H, W, st);
+    up.forward(x, tmp, H, W, st, up_tmp, zeros);
     block.forward(tmp, y, 2 * H, 2 * W, s, st, shortcut);
+}
+
+void DcbChain::load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix)
+{
+    blocks.clear();
+    for (int i = 0; ps.has(prefix + std::to_string(i) + ".dc.0.weight"); ++i) {
+        blocks.emplace_back();
+        blocks.back().load(ps, mem, prefix + std::to_string(i) + ".");
+    }
+    if (blocks.empty()) throw std::invalid_argument("no DepthConvBlocks under " + prefix);
+}
+
+void DcbChain::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
+                       const half_t* q_fused_last) const
+{
+    View cur = x;
+    const int n = static_cast<int>(blocks.size());
+    for (int i = 0; i < n; ++i) {
+        const View out = (i == n - 1) ? y : tmp;
+        blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr);
+        cur = out;
+    }
 }
 
 }  // namespace dcvc

@@ -119,6 +119,28 @@ __global__ void mul_channel_kernel(const half_t* __restrict__ x, int ldx, const 
     *reinterpret_cast<half8*>(y + static_cast<size_t>(pix) * ldy + c0) = o;
 }
 
+// y = x * max(q, 0.5)  or  y = x * fp16(1 / max(q, 0.5)), q a tensor of the same shape
+template <bool RECIP>
+__global__ void scale_clamped_kernel(const half_t* __restrict__ x, int ldx, const half_t* __restrict__ q, int ldq,
+                                     half_t* __restrict__ y, int ldy, int pixels, int C)
+{
+    const int cv = C >> 3;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixels * cv) return;
+    const int pix = i / cv;
+    const int c0 = (i - pix * cv) * 8;
+    const half8 v = *reinterpret_cast<const half8*>(x + static_cast<size_t>(pix) * ldx + c0);
+    const half8 s = *reinterpret_cast<const half8*>(q + static_cast<size_t>(pix) * ldq + c0);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        half_t qc = static_cast<float>(s[e]) > 0.5f ? s[e] : static_cast<half_t>(0.5f);
+        if (RECIP) qc = to_half(1.0f / static_cast<float>(qc));
+        o[e] = hmul(v[e], qc);
+    }
+    *reinterpret_cast<half8*>(y + static_cast<size_t>(pix) * ldy + c0) = o;
+}
+
 inline dim3 grid1d(long long n, int block = 256)
 {
     return dim3(static_cast<unsigned>((n + block - 1) / block));
@@ -174,6 +196,16 @@ void mul_channel(const half_t* x, int ldx, const half_t* q, half_t* y, int ldy, 
     const long long n = static_cast<long long>(pixels) * (C / 8);
     hipLaunchKernelGGL(mul_channel_kernel, grid1d(n), dim3(256), 0, stream, x, ldx, q, y, ldy, pixels, C);
     hip_check(hipGetLastError(), "mul_channel launch");
+}
+
+void scale_clamped(const half_t* x, int ldx, const half_t* q, int ldq, half_t* y, int ldy, int pixels,
+                   int C, bool reciprocal, hipStream_t stream)
+{
+    if (C % 8 != 0) throw std::invalid_argument("scale_clamped: C must be a multiple of 8");
+    const long long n = static_cast<long long>(pixels) * (C / 8);
+    if (reciprocal) hipLaunchKernelGGL(scale_clamped_kernel<true>, grid1d(n), dim3(256), 0, stream, x, ldx, q, ldq, y, ldy, pixels, C);
+    else            hipLaunchKernelGGL(scale_clamped_kernel<false>, grid1d(n), dim3(256), 0, stream, x, ldx, q, ldq, y, ldy, pixels, C);
+    hip_check(hipGetLastError(), "scale_clamped launch");
 }
 
 }  // namespace dcvc

@@ -97,6 +97,11 @@ void crop(const half_t* in, int ldin, int Win, half_t* out, int ldout, int H, in
 void mul_channel(const half_t* x, int ldx, const half_t* q, half_t* y, int ldy, int pixels, int C,
                  hipStream_t stream);
 
+// y = x * max(q, 0.5) (add_and_multiply_with_clamp_min, stream.cu:40-76, after the add) or, with
+// `reciprocal`, y = x * fp16(1 / max(q, 0.5)) (divide_with_clamp, stream.cu:422-443); q is a tensor
+void scale_clamped(const half_t* x, int ldx, const half_t* q, int ldq, half_t* y, int ldy, int pixels,
+                   int C, bool reciprocal, hipStream_t stream);
+
 // ---------------------------------------------------------------- symbol kernels (symbols.hip)
 // Uploads the scale -> Gaussian-table-index lookup table (call once per process before the
 // first symbol kernel and outside any graph capture).
@@ -154,33 +159,39 @@ struct YStepDecRestore {
 };
 void y_step_dec_restore(const YStepDecRestore& d, hipStream_t stream);
 
-// ---------------------------------------------------------------- 2x checkerboard (inter models)
-// mask_0 = first channel half on even (h + w), second half on odd; mask_1 the complement
-// (dmc_ld_proxy.cpp:672-683). A run of 8 channels never straddles the halves, so every 8-channel
-// vector of a pixel belongs to exactly one of the two steps.
+// ---------------------------------------------------------------- full-tensor masked steps (inter models)
+// The inter models quantise ALL channels of y against one scale tensor in `nsteps` masked steps and
+// entropy-code them in one go:
+//   nsteps = 2 (LD):   mask_0 = first channel half on even (h + w), second half on odd; mask_1 the
+//                      complement (dmc_ld_proxy.cpp:672-683)
+//   nsteps = 4 (HT-S): the channel-group x 2x2-position masks of the intra model
+//                      (dmc_hts_proxy.cpp:869-890 == common_model.py:174-195)
+// A run of 8 channels never straddles a channel group, so every 8-channel vector of a pixel belongs
+// to exactly one step.
 //
-// Encoder, step 0: y *= 1/max(q_dec, 0.5) (in place, all positions; divide_with_clamp,
-//   stream.cu:422-443); mask_0 positions: quantise against the hyper means -> symbol, y_hat;
-//   mask_1 positions: y_hat = 0.
-// Encoder, step 1: mask_1 positions: quantise against the spatial-prior means; then everywhere
-//   y_hat = (y_hat) * max(q_dec, 0.5) (process_with_mask<false,true,true>, stream.cu:549-630),
-//   plus the skip flags / per-block counts of ALL symbols (build_index_enc, stream.cu:130-161).
-struct Y2StepEnc {
+// Encoder step k:
+//   k == 0:          y *= 1/max(q_dec, 0.5) in place (divide_with_clamp, stream.cu:422-443) and
+//                    y_hat = 0 at the positions of later steps;
+//   active positions: quantise against `means` -> symbol (<< 8 | scale index), y_hat = y_q + mean
+//                    (process_with_mask_kernel, stream.cu:549-630);
+//   k == nsteps - 1: everywhere y_hat *= max(q_dec, 0.5), plus the skip flags / per-block counts of
+//                    ALL symbols (build_index_enc, stream.cu:130-161).
+struct MaskStepEnc {
     half_t* y = nullptr; int ldy = 0;
     const half_t* q_dec = nullptr; int ldq = 0;
     const half_t* scales = nullptr; int lds = 0;
     const half_t* means = nullptr; int ldm = 0;
     half_t* y_hat = nullptr; int ldh = 0;
-    int16_t* sym = nullptr;                 // [P * C] (symbol << 8) + index, NHWC order
-    uint8_t* cond = nullptr;                // [P * C / 8]   (step 1)
-    int32_t* block_count = nullptr;         // [blocks]      (step 1)
-    int H = 0, W = 0, C = 0, step = 0;
+    int16_t* sym = nullptr;                 // [P * C] NHWC order
+    uint8_t* cond = nullptr;                // [P * C / 8]   (last step)
+    int32_t* block_count = nullptr;         // [blocks]      (last step)
+    int H = 0, W = 0, C = 0, nsteps = 2, step = 0;
     float skip_thres = 0.f;
 };
-void y2_step_enc(const Y2StepEnc& d, hipStream_t stream);
+void mask_step_enc(const MaskStepEnc& d, hipStream_t stream);
 
 // Decoder: table index + skip flag of every symbol (build_index_dec, stream.cu:100-128)
-struct Y2DecIndex {
+struct MaskDecIndex {
     const half_t* scales = nullptr; int lds = 0;
     uint8_t* index = nullptr;
     uint8_t* cond = nullptr;
@@ -188,13 +199,14 @@ struct Y2DecIndex {
     int H = 0, W = 0, C = 0;
     float skip_thres = 0.f;
 };
-void y2_dec_index(const Y2DecIndex& d, hipStream_t stream);
+void mask_dec_index(const MaskDecIndex& d, hipStream_t stream);
 
-// Decoder, step 0: scatter the decoded symbols back (conditional_recover, stream.cu:360-383);
-//   mask_0 positions: y_hat = y_q + means; mask_1 positions: y_hat = 0, y_q parked in `yq`.
-// Decoder, step 1: mask_1 positions: y_hat = yq + spatial-prior means; then everywhere
-//   y_hat *= max(q_dec, 0.5)   (restore_y_kernel<true,true>, stream.cu:686-729).
-struct Y2StepDec {
+// Decoder step k:
+//   k == 0:          scatter the decoded symbols back (conditional_recover, stream.cu:360-383); the
+//                    symbols of later steps are parked in `yq`, their y_hat is zeroed;
+//   active positions: y_hat = y_q + means   (restore_y_kernel, stream.cu:686-729);
+//   k == nsteps - 1: everywhere y_hat *= max(q_dec, 0.5).
+struct MaskStepDec {
     const int8_t* decoded = nullptr;        // compacted symbols (step 0)
     const uint8_t* cond = nullptr;
     const int32_t* block_count = nullptr;
@@ -203,8 +215,8 @@ struct Y2StepDec {
     const half_t* means = nullptr; int ldm = 0;
     const half_t* q_dec = nullptr; int ldq = 0;
     half_t* y_hat = nullptr; int ldh = 0;
-    int H = 0, W = 0, C = 0, step = 0;
+    int H = 0, W = 0, C = 0, nsteps = 2, step = 0;
 };
-void y2_step_dec(const Y2StepDec& d, hipStream_t stream);
+void mask_step_dec(const MaskStepDec& d, hipStream_t stream);
 
 }  // namespace dcvc

@@ -289,12 +289,18 @@ y_step_dec_restore_kernel(const YStepDecRestore d)
     }
 }
 
-// ----------------------------------------------------------------- 2x checkerboard (inter models)
-__device__ __forceinline__ bool active_2x(int step, int h, int w, int ch, int half_c)
+// ----------------------------------------------------------------- full-tensor masked steps (inter models)
+// the step in which channel `ch` of pixel (h, w) is coded
+__device__ __forceinline__ int step_of(int nsteps, int h, int w, int ch, int C)
 {
-    const bool even = ((h ^ w) & 1) == 0;
-    const bool first = ch < half_c;
-    return ((even == first) ? 0 : 1) == step;
+    if (nsteps == 2) {
+        const bool even = ((h ^ w) & 1) == 0;
+        const bool first = ch < (C >> 1);
+        return even == first ? 0 : 1;
+    }
+    const int g = ch / (C >> 2);
+    const int pos = ((h & 1) << 1) | (w & 1);
+    return g == pos ? 0 : g == 3 - pos ? 1 : g == (pos ^ 2) ? 2 : 3;     // inverse of active_group()
 }
 
 __device__ __forceinline__ half_t clamp_min_half(half_t q)
@@ -303,69 +309,72 @@ __device__ __forceinline__ half_t clamp_min_half(half_t q)
 }
 
 __global__ void __launch_bounds__(kBlockThreads)
-y2_step_enc_kernel(const Y2StepEnc d, const LutView lutv, const half_t thres)
+mask_step_enc_kernel(const MaskStepEnc d, const LutView lutv, const half_t thres)
 {
     __shared__ int lds[4];
     const int total = d.H * d.W * d.C;
     const int e0 = (blockIdx.x * kBlockThreads + threadIdx.x) * kElemsPerThread;
+    const bool first = d.step == 0, last = d.step == d.nsteps - 1;
     int kept = 0;
     if (e0 < total) {
         const int pix = e0 / d.C;
         const int ch = e0 - pix * d.C;
         const int h = pix / d.W, w = pix - h * d.W;
-        const bool active = active_2x(d.step, h, w, ch, d.C >> 1);
-        half_t* yp = d.y + static_cast<size_t>(pix) * d.ldy + ch;
-        half_t* yhp = d.y_hat + static_cast<size_t>(pix) * d.ldh + ch;
-        const half8 q8 = *reinterpret_cast<const half8*>(d.q_dec + static_cast<size_t>(pix) * d.ldq + ch);
-        const half8 s8 = *reinterpret_cast<const half8*>(d.scales + static_cast<size_t>(pix) * d.lds + ch);
-        half8 y8 = *reinterpret_cast<const half8*>(yp);
-        if (d.step == 0) {
+        const bool active = step_of(d.nsteps, h, w, ch, d.C) == d.step;
+        if (active || first || last) {
+            half_t* yp = d.y + static_cast<size_t>(pix) * d.ldy + ch;
+            half_t* yhp = d.y_hat + static_cast<size_t>(pix) * d.ldh + ch;
+            const half8 q8 = *reinterpret_cast<const half8*>(d.q_dec + static_cast<size_t>(pix) * d.ldq + ch);
+            const half8 s8 = *reinterpret_cast<const half8*>(d.scales + static_cast<size_t>(pix) * d.lds + ch);
+            half8 y8 = *reinterpret_cast<const half8*>(yp);
+            if (first) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const half_t r = to_half(1.0f / static_cast<float>(clamp_min_half(q8[i])));
-                y8[i] = hmul(y8[i], r);
+                for (int i = 0; i < 8; ++i) {
+                    const half_t r = to_half(1.0f / static_cast<float>(clamp_min_half(q8[i])));
+                    y8[i] = hmul(y8[i], r);
+                }
+                *reinterpret_cast<half8*>(yp) = y8;
             }
-            *reinterpret_cast<half8*>(yp) = y8;
-        }
-        half8 yh = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        unsigned flags = 0;
-        if (active) {
-            const half8 m8 = *reinterpret_cast<const half8*>(d.means + static_cast<size_t>(pix) * d.ldm + ch);
-            typedef short short8 __attribute__((ext_vector_type(8)));
-            short8 s_out;
+            half8 yh = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (active) {
+                const half8 m8 = *reinterpret_cast<const half8*>(d.means + static_cast<size_t>(pix) * d.ldm + ch);
+                typedef short short8 __attribute__((ext_vector_type(8)));
+                short8 s_out;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const half_t y_res = hsub(y8[i], m8[i]);
-                float q = round_half_away(static_cast<float>(y_res));
-                const bool keep = static_cast<float>(s8[i]) > static_cast<float>(thres);
-                q = keep ? q : 0.f;
-                q = fmaxf(fminf(q, 127.f), -128.f);
-                yh[i] = to_half(q + static_cast<float>(m8[i]));
-                s_out[i] = static_cast<short>(static_cast<int>(q) * 256 + scale_to_index(s8[i], lutv));
+                for (int i = 0; i < 8; ++i) {
+                    const half_t y_res = hsub(y8[i], m8[i]);
+                    float q = round_half_away(static_cast<float>(y_res));
+                    const bool keep = static_cast<float>(s8[i]) > static_cast<float>(thres);
+                    q = keep ? q : 0.f;
+                    q = fmaxf(fminf(q, 127.f), -128.f);
+                    yh[i] = to_half(q + static_cast<float>(m8[i]));
+                    s_out[i] = static_cast<short>(static_cast<int>(q) * 256 + scale_to_index(s8[i], lutv));
+                }
+                *reinterpret_cast<short8*>(d.sym + e0) = s_out;
+            } else if (!first) {
+                yh = *reinterpret_cast<const half8*>(yhp);       // an earlier step's result (last step only)
             }
-            *reinterpret_cast<short8*>(d.sym + e0) = s_out;
-        } else if (d.step == 1) {
-            yh = *reinterpret_cast<const half8*>(yhp);
-        }
-        if (d.step == 1) {
+            if (last) {
+                unsigned flags = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                yh[i] = hmul(yh[i], clamp_min_half(q8[i]));
-                flags |= (static_cast<float>(s8[i]) > static_cast<float>(thres) ? 1u : 0u) << i;
+                for (int i = 0; i < 8; ++i) {
+                    yh[i] = hmul(yh[i], clamp_min_half(q8[i]));
+                    flags |= (static_cast<float>(s8[i]) > static_cast<float>(thres) ? 1u : 0u) << i;
+                }
+                d.cond[e0 >> 3] = static_cast<uint8_t>(flags);
+                kept = __popc(flags);
             }
-            d.cond[e0 >> 3] = static_cast<uint8_t>(flags);
-            kept = __popc(flags);
+            *reinterpret_cast<half8*>(yhp) = yh;
         }
-        *reinterpret_cast<half8*>(yhp) = yh;
     }
-    if (d.step == 1) {
+    if (last) {
         const int s = block_sum_256(kept, lds);
         if (threadIdx.x == 0) d.block_count[blockIdx.x] = s;
     }
 }
 
 __global__ void __launch_bounds__(kBlockThreads)
-y2_dec_index_kernel(const Y2DecIndex d, const LutView lutv, const half_t thres)
+mask_dec_index_kernel(const MaskDecIndex d, const LutView lutv, const half_t thres)
 {
     __shared__ int lds[4];
     const int total = d.H * d.W * d.C;
@@ -392,14 +401,15 @@ y2_dec_index_kernel(const Y2DecIndex d, const LutView lutv, const half_t thres)
 }
 
 __global__ void __launch_bounds__(kBlockThreads)
-y2_step_dec_kernel(const Y2StepDec d)
+mask_step_dec_kernel(const MaskStepDec d)
 {
     __shared__ int lds[4];
     const int total = d.H * d.W * d.C;
     const int e0 = (blockIdx.x * kBlockThreads + threadIdx.x) * kElemsPerThread;
+    const bool first = d.step == 0, last = d.step == d.nsteps - 1;
     typedef signed char char8 __attribute__((ext_vector_type(8)));
     char8 q8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (d.step == 0) {
+    if (first) {
         unsigned flags = 0;
         if (e0 < total) flags = d.cond[e0 >> 3];
         int step_base;
@@ -414,20 +424,21 @@ y2_step_dec_kernel(const Y2StepDec d)
     const int pix = e0 / d.C;
     const int ch = e0 - pix * d.C;
     const int h = pix / d.W, w = pix - h * d.W;
-    const bool active = active_2x(d.step, h, w, ch, d.C >> 1);
+    const bool active = step_of(d.nsteps, h, w, ch, d.C) == d.step;
+    if (!(active || first || last)) return;
     half_t* yhp = d.y_hat + static_cast<size_t>(pix) * d.ldh + ch;
     half8 yh = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (active) {
-        if (d.step == 1) q8 = *reinterpret_cast<const char8*>(d.yq + e0);
+        if (!first) q8 = *reinterpret_cast<const char8*>(d.yq + e0);
         const half8 m8 = *reinterpret_cast<const half8*>(d.means + static_cast<size_t>(pix) * d.ldm + ch);
 #pragma unroll
         for (int i = 0; i < 8; ++i) yh[i] = to_half(static_cast<float>(q8[i]) + static_cast<float>(m8[i]));
-    } else if (d.step == 0) {
+    } else if (first) {
         *reinterpret_cast<char8*>(d.yq + e0) = q8;
     } else {
         yh = *reinterpret_cast<const half8*>(yhp);
     }
-    if (d.step == 1) {
+    if (last) {
         const half8 qd = *reinterpret_cast<const half8*>(d.q_dec + static_cast<size_t>(pix) * d.ldq + ch);
 #pragma unroll
         for (int i = 0; i < 8; ++i) yh[i] = hmul(yh[i], clamp_min_half(qd[i]));
@@ -522,30 +533,41 @@ void y_step_dec_restore(const YStepDecRestore& d, hipStream_t stream)
     hip_check(hipGetLastError(), "y_step_dec_restore launch");
 }
 
-void y2_step_enc(const Y2StepEnc& d, hipStream_t stream)
+namespace {
+
+void check_mask_steps(int C, int nsteps, int step, const char* who)
 {
-    if (d.C % 16 != 0 || (d.step != 0 && d.step != 1)) throw std::invalid_argument("y2_step_enc: bad C / step");
-    const int count = d.H * d.W * d.C;
-    hipLaunchKernelGGL(y2_step_enc_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d,
-                       lut_view(), static_cast<half_t>(d.skip_thres));
-    hip_check(hipGetLastError(), "y2_step_enc launch");
+    if ((nsteps != 2 && nsteps != 4) || step < 0 || step >= nsteps || C % (8 * nsteps) != 0) {
+        throw std::invalid_argument(std::string(who) + ": bad C / nsteps / step");
+    }
 }
 
-void y2_dec_index(const Y2DecIndex& d, hipStream_t stream)
+}  // namespace
+
+void mask_step_enc(const MaskStepEnc& d, hipStream_t stream)
 {
-    if (d.C % 16 != 0) throw std::invalid_argument("y2_dec_index: C must be a multiple of 16");
+    check_mask_steps(d.C, d.nsteps, d.step, "mask_step_enc");
     const int count = d.H * d.W * d.C;
-    hipLaunchKernelGGL(y2_dec_index_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d,
+    hipLaunchKernelGGL(mask_step_enc_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d,
                        lut_view(), static_cast<half_t>(d.skip_thres));
-    hip_check(hipGetLastError(), "y2_dec_index launch");
+    hip_check(hipGetLastError(), "mask_step_enc launch");
 }
 
-void y2_step_dec(const Y2StepDec& d, hipStream_t stream)
+void mask_dec_index(const MaskDecIndex& d, hipStream_t stream)
 {
-    if (d.C % 16 != 0 || (d.step != 0 && d.step != 1)) throw std::invalid_argument("y2_step_dec: bad C / step");
+    if (d.C % 8 != 0) throw std::invalid_argument("mask_dec_index: C must be a multiple of 8");
     const int count = d.H * d.W * d.C;
-    hipLaunchKernelGGL(y2_step_dec_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d);
-    hip_check(hipGetLastError(), "y2_step_dec launch");
+    hipLaunchKernelGGL(mask_dec_index_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d,
+                       lut_view(), static_cast<half_t>(d.skip_thres));
+    hip_check(hipGetLastError(), "mask_dec_index launch");
+}
+
+void mask_step_dec(const MaskStepDec& d, hipStream_t stream)
+{
+    check_mask_steps(d.C, d.nsteps, d.step, "mask_step_dec");
+    const int count = d.H * d.W * d.C;
+    hipLaunchKernelGGL(mask_step_dec_kernel, dim3(grid_for(count)), dim3(kBlockThreads), 0, stream, d);
+    hip_check(hipGetLastError(), "mask_step_dec launch");
 }
 
 void round_z(const half_t* z, half_t* z_hat, int8_t* z_i8, int count, hipStream_t stream)

@@ -118,11 +118,14 @@ class CompressionModel(nn.Module):
     def __init__(self):
         super().__init__()
         dcvc_amd.install_plugin()
-        for name, shape in self._SPEC().items():
+        for name, shape in self._spec().items():
             _register(self, name, torch.zeros(shape))
         self.proxy = None
         self.skip_thres = 0.0
         self._cdf = None
+
+    def _spec(self):
+        return self._SPEC()
 
     @staticmethod
     def qp_num():
@@ -215,3 +218,20 @@ class DMC(CompressionModel):
             np.frombuffer(bit_stream, dtype=np.uint8), qp, sps["height"], sps["width"], ec_part,
             bool(reset_feature_memory))
         return {"x_hat": x_hat}
+
+
+class DMCHT(DMC):
+    """video_model_ht.py:320-470 (inference subset): the hierarchical inter models, 8 pictures per
+    call. ``model_structure`` is "hts" (DMCHTSProxy) or "htl" (DMCHTLProxy); the reference spells
+    it ``DMC(ModelStructure.HTS)`` in its own module."""
+
+    def __init__(self, model_structure="hts"):
+        ms = str(getattr(model_structure, "name", model_structure)).lower()
+        if ms not in ("hts", "htl"):
+            raise ValueError("model_structure must be 'hts' or 'htl'")
+        self.is_hts = ms == "hts"
+        self._PROXY = "DMCHTSProxy" if self.is_hts else "DMCHTLProxy"
+        super().__init__()
+
+    def _spec(self):
+        return arch.dmc_ht_spec(self.is_hts)

@@ -44,6 +44,19 @@ _LD = dict(
     debug_read=_lib.fn("dcvc_dmcld_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
 )
 
+_HT = dict(
+    create=_lib.fn("dcvc_dmcht_create", _vp, [_ci]),
+    destroy=_lib.fn("dcvc_dmcht_destroy", None, [_vp]),
+    set_param=_lib.fn("dcvc_dmcht_set_param", _ci, _SET_PARAM_ARGS),
+    add_ref=_lib.fn("dcvc_dmcht_add_ref_feature_from_frame", _ci, [_vp, _vp, _ci, _ci, _ci, _vp]),
+    compress=_lib.fn("dcvc_dmcht_compress", _ci, [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
+    get_stream=_lib.fn("dcvc_dmcht_get_stream", ctypes.c_int64, [_vp, _vp, ctypes.c_size_t]),
+    decompress=_lib.fn("dcvc_dmcht_decompress", _ci,
+                       [_vp, _vp, ctypes.c_size_t, _ci, _ci, _ci, _ci, _ci, _vp, _vp]),
+    use_graphs=_lib.fn("dcvc_dmcht_set_use_graphs", _ci, [_vp, _ci]),
+    debug_read=_lib.fn("dcvc_dmcht_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
+)
+
 _DTYPES = {torch.float16: 0, torch.float32: 1, torch.int32: 2}
 
 
@@ -88,8 +101,10 @@ class _Proxy:
     """Handle ownership + the calls every proxy class has."""
     _FN = None
 
+    _CREATE_ARGS = ()
+
     def __init__(self):
-        self._h = self._FN["create"]()
+        self._h = self._FN["create"](*self._CREATE_ARGS)
         if not self._h:
             raise _lib.DcvcError(_lib.lib().dcvc_last_error().decode())
         self._x_hat = None
@@ -180,3 +195,46 @@ class DMCLDProxy(_Proxy):
                                      1 if reset_feature_memory else 0,
                                      ctypes.c_void_p(x_hat.data_ptr()), _stream_ptr()))
         return x_hat
+
+
+class _DMCHTProxy(_Proxy):
+    """The hierarchical inter codecs: 8 pictures per call (video_model_ht.py:16 g_frame_delay)."""
+    _FN = _HT
+    FRAMES = 8
+
+    def add_ref_feature_from_frame(self, frame, apply_feature_adaptor=True):
+        frame, fp = _nhwc_ptr(frame, 3)
+        _lib.check(_HT["add_ref"](self._h, fp, int(frame.shape[2]), int(frame.shape[3]),
+                                  1 if apply_feature_adaptor else 0, _stream_ptr()))
+
+    def compress(self, x, qp, reset_feature_memory, padding_b, padding_r):
+        """x: [1, 24, H, W] (8 pictures x 3 planes) -> (np.ndarray[uint8] bit stream, ec_parallel)"""
+        x, xp = _nhwc_ptr(x, 3 * self.FRAMES)
+        ec = _lib.check(_HT["compress"](self._h, xp, int(x.shape[2]), int(x.shape[3]), int(qp),
+                                        1 if reset_feature_memory else 0, int(padding_b), int(padding_r),
+                                        _stream_ptr()))
+        return self._stream_bytes(), int(ec)
+
+    def decompress(self, bit_stream, qp, height, width, entropy_coder_parallel, reset_feature_memory):
+        """-> list of 8 x_hat [1, 3, ceil16(H), ceil16(W)] (proxy-owned, overwritten by the next call)"""
+        bs = np.ascontiguousarray(bit_stream, dtype=np.uint8)
+        device = torch.device("cuda", torch.cuda.current_device())
+        h16, w16 = (int(height) + 15) // 16 * 16, (int(width) + 15) // 16 * 16
+        if self._x_hat is None or tuple(self._x_hat.shape) != (self.FRAMES, 3, h16, w16) or self._x_hat.device != device:
+            self._x_hat = torch.empty((self.FRAMES, 3, h16, w16), dtype=torch.float16, device=device).contiguous(
+                memory_format=torch.channels_last)
+        _lib.check(_HT["decompress"](self._h, bs.ctypes.data_as(_vp), bs.size, int(qp), int(height),
+                                     int(width), int(entropy_coder_parallel),
+                                     1 if reset_feature_memory else 0,
+                                     ctypes.c_void_p(self._x_hat.data_ptr()), _stream_ptr()))
+        return [self._x_hat[i:i + 1] for i in range(self.FRAMES)]
+
+
+class DMCHTSProxy(_DMCHTProxy):
+    """bind.cpp:17-23 / dmc_hts_proxy.h."""
+    _CREATE_ARGS = (1,)
+
+
+class DMCHTLProxy(_DMCHTProxy):
+    """bind.cpp:24-30 / dmc_htl_proxy.h."""
+    _CREATE_ARGS = (0,)

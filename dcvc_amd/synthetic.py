@@ -41,11 +41,48 @@ _GAIN_OVERRIDES_INTER = (
 )
 
 
+# hierarchical inter models (HT-S / HT-L): deeper chains at width 512
+_GAIN_OVERRIDES_HT = (
+    ("feature_adaptor_i.conv.0.adaptor.weight", 2.0),
+    ("feature_adaptor_m.conv.0.adaptor.weight", 0.4),
+    ("encoder.conv1.0.adaptor.weight", 1.0),
+    ("encoder.down.weight", 2.5),
+    ("hyper_encoder.conv.0.dc.0.weight", 0.5),
+    ("hyper_decoder.conv.2.ffn.2.weight", 0.5),
+    ("y_prior_fusion.conv.3.weight", 0.35),
+    ("y_spatial_prior.conv.3.weight", 0.35),
+    ("decoder.up.conv.0.weight", 0.3),
+    ("decoder.conv1.0.adaptor.weight", 0.5),
+    ("recon_head.conv2.0.3.weight", 0.1), ("recon_head.conv2.1.3.weight", 0.1),
+    ("recon_head.conv2.2.3.weight", 0.1), ("recon_head.conv2.3.3.weight", 0.1),
+    ("recon_head.conv2.4.3.weight", 0.1), ("recon_head.conv2.5.3.weight", 0.1),
+    ("recon_head.conv2.6.3.weight", 0.1), ("recon_head.conv2.7.3.weight", 0.1),
+    ("recon_head.conv.0.5.weight", 0.1), ("recon_head.conv.1.5.weight", 0.1),
+    ("recon_head.conv.2.5.weight", 0.1), ("recon_head.conv.3.5.weight", 0.1),
+    ("recon_head.conv.4.5.weight", 0.1), ("recon_head.conv.5.5.weight", 0.1),
+    ("recon_head.conv.6.5.weight", 0.1), ("recon_head.conv.7.5.weight", 0.1),
+)
+
+
+# extra damping for HT-L on top of the HT set (full-width blocks with block-level shortcuts amplify more)
+_GAIN_OVERRIDES_HTL_EXTRA = (
+    ("feature_adaptor_m.conv.0.adaptor.weight", 0.55),
+    ("hyper_encoder.conv.1.down.weight", 0.5),
+    ("hyper_encoder.conv.2.down.weight", 0.5),
+    ("hyper_decoder.conv.0.up.conv.0.weight", 0.3),
+    ("hyper_decoder.conv.1.up.conv.0.weight", 0.5),
+    ("decoder.conv1.0.adaptor.weight", 0.6),
+)
+
+
 def synthetic_state_dict(spec, seed=0, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     sd = {}
     inter = "q_encoder" in spec
-    overrides = _GAIN_OVERRIDES_INTER if inter else _GAIN_OVERRIDES
+    ht = inter and "y_spatial_prior_reduction.weight" in spec
+    overrides = _GAIN_OVERRIDES_HT if ht else _GAIN_OVERRIDES_INTER if inter else _GAIN_OVERRIDES
+    if ht and "recon_head.conv.0.0.dc.0.weight" in spec:
+        overrides = overrides + _GAIN_OVERRIDES_HTL_EXTRA
     for name, shape in spec.items():
         if name.startswith("bit_estimator_z."):
             # spread wide enough that table lengths vary across channels (entropy_models.py:113-149)

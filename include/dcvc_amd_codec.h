@@ -97,6 +97,35 @@ int dcvc_dmcld_set_use_graphs(dcvc_dmcld* c, int on);
  * "feature_i", "symbols", "totals"); dense copy, returns the size in bytes. */
 int64_t dcvc_dmcld_debug_read(dcvc_dmcld* c, const char* name, void* dst, size_t cap, void* stream);
 
+/* ------------------------------------------------------------------ DMCHTSProxy / DMCHTLProxy
+ * bind.cpp:17-30 / dmc_hts_proxy.h, dmc_htl_proxy.h: the hierarchical inter codecs, 8 pictures
+ * ("chunk") per call. is_hts != 0 creates the HT-S codec, 0 the HT-L codec; set_param rejects a
+ * state_dict of the other structure. */
+typedef struct dcvc_dmcht dcvc_dmcht;
+
+dcvc_dmcht* dcvc_dmcht_create(int is_hts);
+void dcvc_dmcht_destroy(dcvc_dmcht* c);
+int dcvc_dmcht_set_param(dcvc_dmcht* c, int n, const char* const* names, const void* const* data,
+                         const int* dtypes, const int* ndims, const int64_t* dims, float skip_thres);
+/* dmc_hts_proxy.cpp:492-502 */
+int dcvc_dmcht_add_ref_feature_from_frame(dcvc_dmcht* c, const void* frame, int height, int width,
+                                          int apply_adaptor, void* stream);
+/* DMCHT*Proxy.compress(x, qp, reset_feature_memory, padding_b, padding_r), dmc_hts_proxy.cpp:504-585.
+ * x: device fp16 [height][width][24] = the channels_last memory of the reference's [1, 24, H, W]
+ * input (8 pictures x 3 planes). Returns ec_parallel. */
+int dcvc_dmcht_compress(dcvc_dmcht* c, const void* x, int height, int width, int qp,
+                        int reset_feature_memory, int padding_b, int padding_r, void* stream);
+int64_t dcvc_dmcht_get_stream(dcvc_dmcht* c, uint8_t* dst, size_t cap);
+/* DMCHT*Proxy.decompress(...) -> list of 8 x_hat, dmc_hts_proxy.cpp:587-710. x_hat: device fp16
+ * [8][ceil16(height)][ceil16(width)][3], the 8 reconstructions back to back. */
+int dcvc_dmcht_decompress(dcvc_dmcht* c, const uint8_t* bit_stream, size_t nbytes, int qp, int height,
+                          int width, int ec_parallel, int reset_feature_memory, void* x_hat,
+                          void* stream);
+int dcvc_dmcht_set_use_graphs(dcvc_dmcht* c, int on);
+/* Test hook ("y", "y_hat", "common", "z_i8", "memory", "feature_p", "ctx", "feature_i", "symbols",
+ * "totals"). */
+int64_t dcvc_dmcht_debug_read(dcvc_dmcht* c, const char* name, void* dst, size_t cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

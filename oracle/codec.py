@@ -96,9 +96,29 @@ class Net:
         out = nn.conv_kxk(x, w2, self.sd[p + "down.bias"], 2, 2, 0)
         return self.dcb(out, p + "conv.", shortcut=shortcut)
 
+    def subpel(self, x, p):
+        """SubpelConv2xProxy::forward (layers_proxy.cpp:269-276): without bias a 2x2 stride-2
+        transposed conv; with bias a k x k conv + bias (rounded to fp16) + pixel_shuffle(2)."""
+        w = self.sd[p + "conv.0.weight"]
+        if p + "conv.0.bias" not in self.sd:
+            return nn.subpel_conv1x1(x, w)
+        k = w.shape[-1]
+        out = nn.conv_kxk(x, w, self.sd[p + "conv.0.bias"], k, 1, k // 2)
+        return nn.pixel_shuffle(out, 2)
+
     def rb_upsample(self, x, p, shortcut=True):
-        out = nn.subpel_conv1x1(x, self.sd[p + "up.conv.0.weight"])
-        return self.dcb(out, p + "conv.", shortcut=shortcut)
+        return self.dcb(self.subpel(x, p + "up."), p + "conv.", shortcut=shortcut)
+
+    def chain(self, x, prefix, q_last=None):
+        """nn.Sequential of DepthConvBlocks prefix0., prefix1., ...; q_last: scale fused into the
+        last block (DepthConvBlockProxy::forward(x, quant), layers_proxy.cpp:92-95)."""
+        n = 0
+        while prefix + "%d.dc.0.weight" % n in self.sd:
+            n += 1
+        assert n > 0, prefix
+        for i in range(n):
+            x = self.dcb(x, prefix + "%d." % i, q=q_last if i == n - 1 else None)
+        return x
 
 
 class DMCIOracle:
@@ -400,3 +420,197 @@ class DMCLDOracle:
         self.feature_i = head
         self.memory_has_value = not reset_feature_memory
         return x_hat
+
+
+class DMCHTOracle:
+    """CPU restatement of DMCHTSProxy / DMCHTLProxy (dmc_hts_proxy.cpp:492-710,
+    dmc_htl_proxy.cpp:583-905): hierarchical inter codecs, 8 pictures per call. Networks:
+    video_model_ht.py:26-317. HT-S codes all of y against one scale tensor in four masked steps
+    (spatial prior predicts means only); HT-L runs the intra model's 4-step scheme (scales and
+    means from the spatial prior, one symbol group per step)."""
+    FRAMES, CH_SRC_I, CH_Y, CH_Z, CH_D, CH_M = 8, 192, 256, 128, 512, 512
+
+    def __init__(self, state_dict, skip_thres, cdf_tables=None, is_hts=True):
+        self.sd = to_np_state_dict(state_dict)
+        self.net = Net(self.sd)
+        self.is_hts = bool(is_hts)
+        self.skip_thres = float(skip_thres)
+        self.tables = orc_rans.Tables()
+        if cdf_tables is not None:
+            self.tables.set_cdf(cdf_tables[0], cdf_tables[1], 0)
+            self.tables.set_cdf(cdf_tables[2], cdf_tables[3], 1)
+        self.feature_i = self.memory = self.feature_p = self.ctx = None
+        self.memory_has_value = False
+        self.debug = {}
+
+    # ---- sub-networks
+    def fa_i(self, x):
+        return self.net.chain(x, "feature_adaptor_i.conv.")
+
+    def fa_m(self, memory, feature):
+        return self.net.chain(np.concatenate([memory, feature], axis=-1), "feature_adaptor_m.conv.")
+
+    def fe(self, memory):
+        return self.net.chain(memory, "feature_extractor.conv.")
+
+    def tpe(self, memory, qp):
+        x = nn.mul_channel(memory, self.sd["q_feature"][qp])             # multiply_with_broadcast
+        return self.net.rb_stride2(x, "temporal_prior_encoder.conv.", shortcut=not self.is_hts)
+
+    def encoder(self, xu, ctx, qp):
+        out = self.net.chain(np.concatenate([xu, ctx], axis=-1), "encoder.conv1.", q_last=self.sd["q_encoder"][qp])
+        return nn.conv_kxk(out, self.sd["encoder.down.weight"], self.sd["encoder.down.bias"], 3, 2, 1)
+
+    def hyper_encoder(self, y_pad):
+        n, sc = self.net, not self.is_hts
+        out = n.dcb(y_pad, "hyper_encoder.conv.0.")
+        out = n.rb_stride2(out, "hyper_encoder.conv.1.", shortcut=sc)
+        return n.rb_stride2(out, "hyper_encoder.conv.2.", shortcut=sc)
+
+    def hyper_decoder(self, z_hat):
+        n, sc = self.net, not self.is_hts
+        out = n.rb_upsample(z_hat, "hyper_decoder.conv.0.", shortcut=sc)
+        out = n.rb_upsample(out, "hyper_decoder.conv.1.", shortcut=sc)
+        return n.dcb(out, "hyper_decoder.conv.2.")
+
+    def prior_fusion(self, hyper, temporal):
+        out = self.net.chain(np.concatenate([hyper, temporal], axis=-1), "y_prior_fusion.conv.")
+        return self.net.conv1x1(out, "y_prior_fusion.conv.3.")
+
+    def spatial_prior(self, y_hat_so_far, reduced, k):
+        n = self.net
+        out = n.dcb(np.concatenate([y_hat_so_far, reduced], axis=-1), "y_spatial_prior_adaptor_%d." % k)
+        out = n.chain(out, "y_spatial_prior.conv.")
+        return n.conv1x1(out, "y_spatial_prior.conv.3.")
+
+    def decoder(self, y_hat, ctx, qp):
+        up = self.net.subpel(y_hat, "decoder.up.")
+        return self.net.chain(np.concatenate([up, ctx], axis=-1), "decoder.conv1.", q_last=self.sd["q_decoder"][qp])
+
+    def recon_head(self, feature, only_last=False):
+        """-> (list of 8 x_hat [H16*16, W16*16, 3], head output of picture 7 [H8, W8, 192])"""
+        n = self.net
+        outs, head = [], None
+        common = None
+        for i in range(self.FRAMES):
+            if only_last and i != self.FRAMES - 1:
+                continue
+            if self.is_hts:
+                if i % 2 == 0 or only_last:
+                    common = n.dcb(feature, "recon_head.conv1.%d.0." % (i // 2))
+                out = n.chain(common, "recon_head.conv2.%d." % i)
+                head = n.conv1x1(out, "recon_head.conv2.%d.3." % i)
+            else:
+                out = n.chain(feature, "recon_head.conv.%d." % i)
+                head = n.conv1x1(out, "recon_head.conv.%d.5." % i)
+            outs.append(np.clip(nn.pixel_shuffle(head, 8), F16(-0.5), F16(0.5)).astype(F16))
+        return outs, head
+
+    # ---- add_ref_feature_from_frame (dmc_hts_proxy.cpp:492-502)
+    def add_ref_feature_from_frame(self, frame, apply_adaptor):
+        self.feature_i = nn.pixel_unshuffle(frame.astype(F16), 8)
+        if apply_adaptor:
+            self.memory = self.fa_i(self.feature_i)
+            self.ctx = self.fe(self.memory)
+        self.memory_has_value = bool(apply_adaptor)
+
+    def _common(self, z_hat, qp):
+        temporal = self.tpe(self.memory, qp)
+        hyper = self.hyper_decoder(z_hat)[:temporal.shape[0], :temporal.shape[1]]
+        common = self.prior_fusion(hyper, temporal)
+        C = self.CH_Y
+        return common, common[..., :C], common[..., C:2 * C], common[..., 2 * C:]
+
+    # ---- compress (dmc_hts_proxy.cpp:504-585, dmc_htl_proxy.cpp:595-716)
+    def compress(self, x, qp, reset_feature_memory):
+        """x: fp16 [H, W, 24] (8 pictures x 3 planes, picture-major)."""
+        H, W, _ = x.shape
+        C = self.CH_Y
+        pr, pb = get_padding_size(H, W, 16)
+        xu = nn.pixel_unshuffle(replicate_pad(x.astype(F16), pb, pr), 8)
+        y = self.encoder(xu, self.ctx, qp)
+        yH, yW, _ = y.shape
+        pr4, pb4 = get_padding_size(yH, yW, 4)
+        z = self.hyper_encoder(replicate_pad(y, pb4, pr4))
+        z_hat, z_i8 = sym.round_z(z)
+        common, q_dec, scales, means = self._common(z_hat, qp)
+        y = sym.divide_with_clamp(y, q_dec)
+        reduced = self.net.conv1x1(common, "y_spatial_prior_reduction.")
+        masks = sym.get_mask_4x(yH, yW, C)
+        y_hat_so_far = None
+        y_q_all = None
+        y_syms = []
+        for k in range(4):
+            y_q, y_hat, s_hat = sym.process_with_mask(y, scales, means, masks[k], self.skip_thres)
+            if not self.is_hts:
+                comb, keep = sym.build_index_enc(sym.fold4(y_q), sym.fold4(s_hat), self.skip_thres)
+                y_syms.append(comb[keep])
+            y_q_all = y_q if y_q_all is None else (y_q_all + y_q).astype(F16)
+            y_hat_so_far = y_hat if y_hat_so_far is None else (y_hat_so_far + y_hat).astype(F16)
+            if k < 3:
+                sp = self.spatial_prior(y_hat_so_far, reduced, k + 1)
+                if self.is_hts:
+                    means = sp
+                else:
+                    scales, means = sp[..., :C], sp[..., C:]
+        y_hat = (y_hat_so_far * sym.clamp_min_half(q_dec)).astype(F16)
+        if self.is_hts:
+            comb, keep = sym.build_index_enc(y_q_all, scales, self.skip_thres)
+            y_syms = [comb[keep]]
+        total = sum(len(s) for s in y_syms)
+        ec = compute_ec_parallel(total)
+        segs = [("y", s) for s in reversed(y_syms)]
+        segs.append(("z", z_i8.reshape(-1), qp * self.CH_Z, self.CH_Z))
+        stream = orc_rans.encode(self.tables, segs, ec)
+        self.debug = dict(y=y, y_hat=y_hat, z_i8=z_i8, y_syms=y_syms)
+        # lambda_enc_1
+        self.feature_p = self.decoder(y_hat, self.ctx, qp)
+        if reset_feature_memory:
+            _, head = self.recon_head(self.feature_p, only_last=True)     # forward_reset
+            self.memory = self.fa_i(head)
+        else:
+            self.memory = self.fa_m(self.memory, self.feature_p)
+        self.ctx = self.fe(self.memory)
+        return dict(bit_stream=stream.tobytes(), ec_parallel=ec)
+
+    # ---- decompress (dmc_hts_proxy.cpp:587-710, dmc_htl_proxy.cpp:718-905)
+    def decompress(self, bit_stream, qp, height, width, ec_parallel, reset_feature_memory):
+        C = self.CH_Y
+        zH, zW = (height + 63) // 64, (width + 63) // 64
+        if self.memory_has_value:
+            self.memory = self.fa_m(self.memory, self.feature_p)
+        else:
+            self.memory = self.fa_i(self.feature_i)
+        dec = orc_rans.Decoder(self.tables, np.frombuffer(bit_stream, dtype=np.uint8), ec_parallel)
+        z_i8 = dec.decode_z(self.CH_Z * zH * zW, qp * self.CH_Z, self.CH_Z).reshape(zH, zW, self.CH_Z)
+        common, q_dec, scales, means = self._common(z_i8.astype(F16), qp)
+        yH, yW = scales.shape[:2]
+        reduced = self.net.conv1x1(common, "y_spatial_prior_reduction.")
+        self.ctx = self.fe(self.memory)
+        masks = sym.get_mask_4x(yH, yW, C)
+        y_hat_so_far = None
+        if self.is_hts:
+            idx, keep = sym.build_index_dec(scales, self.skip_thres)
+            y_q_r = sym.recover(dec.decode_y(idx[keep]), keep, (yH, yW, C))
+        for k in range(4):
+            if self.is_hts:
+                y_hat = sym.restore_y(y_q_r, means, masks[k])
+            else:
+                s_r = sym.fold4(np.where(masks[k], scales, F16(0)).astype(F16))
+                idx, keep = sym.build_index_dec(s_r, self.skip_thres)
+                y_q_g = sym.recover(dec.decode_y(idx[keep]), keep, (yH, yW, C // 4))
+                y_hat = sym.restore_y_4x(y_q_g, means, masks[k])
+            y_hat_so_far = y_hat if y_hat_so_far is None else (y_hat_so_far + y_hat).astype(F16)
+            if k < 3:
+                sp = self.spatial_prior(y_hat_so_far, reduced, k + 1)
+                if self.is_hts:
+                    means = sp
+                else:
+                    scales, means = sp[..., :C], sp[..., C:]
+        dec.close()
+        y_hat = (y_hat_so_far * sym.clamp_min_half(q_dec)).astype(F16)
+        self.feature_p = self.decoder(y_hat, self.ctx, qp)
+        x_hats, head = self.recon_head(self.feature_p)
+        self.feature_i = head
+        self.memory_has_value = not reset_feature_memory
+        return x_hats

@@ -29,10 +29,31 @@ def dmc_ld_model(seed=0, skip_thres=0.0):
     return _CACHE[key]
 
 
+def dmc_ht_model(structure="hts", seed=0, skip_thres=0.0):
+    """Seeded synthetic hierarchical inter model ("hts" / "htl") with its CDF tables."""
+    key = (structure, seed, skip_thres)
+    if key not in _CACHE:
+        m = models.DMCHT(structure)
+        m.load_state_dict(synthetic.synthetic_state_dict(arch.dmc_ht_spec(structure == "hts"), seed))
+        m.update(skip_thres)
+        _CACHE[key] = m
+    return _CACHE[key]
+
+
 def oracle_for(model):
     from oracle import codec
-    cls = codec.DMCLDOracle if isinstance(model, models.DMC) else codec.DMCIOracle
-    return cls(model.state_dict(), model.skip_thres, model.get_cdf_info())
+    args = (model.state_dict(), model.skip_thres, model.get_cdf_info())
+    if isinstance(model, models.DMCHT):
+        return codec.DMCHTOracle(*args, is_hts=model.is_hts)
+    if isinstance(model, models.DMC):
+        return codec.DMCLDOracle(*args)
+    return codec.DMCIOracle(*args)
+
+
+def chunk(height, width, first_index, seed=0, frames=8):
+    """8 consecutive synthetic pictures as fp16 [H, W, 24] (picture-major channels, the
+    channels_last view of the reference's [1, 24, H, W] chunk, test_video.py:95-110)."""
+    return np.concatenate([picture(height, width, first_index + j, seed) for j in range(frames)], axis=-1)
 
 
 def force_ld_state(o, feature, memory):
@@ -46,7 +67,8 @@ def force_ld_state(o, feature, memory):
         o.memory = o.fa_m(memory, feature)
         o.memory_has_value = True
     o.ctx = o.fe(o.memory)
-    o.temporal = o.tpe(o.memory)
+    if hasattr(o, "temporal"):                  # LD keeps the temporal prior as state
+        o.temporal = o.tpe(o.memory)
 
 
 def picture(height, width, index=0, seed=0):

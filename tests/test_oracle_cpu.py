@@ -126,6 +126,64 @@ def test_ld_oracle_sequence_closure(golden_ld):
         assert p > 20.0
 
 
+# ------------------------------------------------------------------------------ inter models (HT-S / HT-L)
+@pytest.fixture(scope="module")
+def golden_ht(golden_dir):
+    return np.load(os.path.join(golden_dir, "dmcht_golden.npz"))
+
+
+def test_ht_parameter_inventory():
+    from dcvc_amd import arch
+    assert arch.param_count(arch.dmc_ht_spec(True)) == 81157632       # strict=True load in make_dmcht_golden.py
+    assert arch.param_count(arch.dmc_ht_spec(False)) == 120538368
+    assert arch.dmc_ht_spec(False)["decoder.up.conv.0.weight"] == (2048, 256, 3, 3)
+    assert "hyper_decoder.conv.0.up.conv.0.bias" not in arch.dmc_ht_spec(True)
+
+
+@pytest.mark.parametrize("structure,chunks,floor", [("hts", (0, 1), 42.0), ("htl", (1, 2), 52.0)])
+def test_ht_oracle_follows_reference_graph(golden_ht, structure, chunks, floor):
+    """Single chunks (8 pictures) started from the reference graph's temporal state, incl. a
+    chunk that resets the memory and the chunk after it. The HT-S floor is lower: its one-shot
+    4-step scheme turns every rounding-tie flip of an early step into shifted means later on
+    (measured: ~1 % flipped symbols, everything else within fp16 noise)."""
+    from codec_util import dmc_ht_model, force_ld_state
+    from oracle import codec
+    g = golden_ht
+    m = dmc_ht_model(structure)
+    plan = g[structure + "_plan"]
+    for i in chunks:
+        qp, reset = int(plan[i][0]), bool(plan[i][1])
+        o = codec.DMCHTOracle(m.state_dict(), -60000.0, m.get_cdf_info(), is_hts=m.is_hts)
+        if i == 0:
+            o.add_ref_feature_from_frame(g[structure + "_ref"], True)
+        else:
+            key = "%s_mem%d" % (structure, i - 1)
+            force_ld_state(o, g["%s_feat%d" % (structure, i - 1)], g[key] if key in g else None)
+        o.compress(g["%s_x%d" % (structure, i)], qp, reset)
+        x_hat = np.concatenate(o.recon_head(o.feature_p)[0], axis=-1)
+        ref = np.clip(g["%s_xhat%d" % (structure, i)].astype(np.float32), -0.5, 0.5)
+        p = psnr(x_hat, ref)
+        print(structure, "chunk", i, "PSNR oracle vs reference graph: %.2f dB" % p)
+        assert p > floor
+
+
+def test_ht_oracle_sequence_closure(golden_ht):
+    """Free-running HT-S encoder and decoder oracles over two chunks with a reset in between."""
+    from codec_util import dmc_ht_model, oracle_for
+    g = golden_ht
+    m = dmc_ht_model("hts", skip_thres=0.15)
+    enc, dec = oracle_for(m), oracle_for(m)
+    enc.add_ref_feature_from_frame(g["hts_ref"], True)
+    dec.add_ref_feature_from_frame(g["hts_ref"], False)
+    for i, reset in ((0, True), (1, False)):
+        x = g["hts_x%d" % i]
+        r = enc.compress(x, 30, reset)
+        xd = dec.decompress(r["bit_stream"], 30, x.shape[0], x.shape[1], r["ec_parallel"], reset)
+        assert len(xd) == 8 and xd[0].shape == (64, 64, 3)
+        assert np.array_equal(dec.feature_p, enc.feature_p)
+        assert np.array_equal(np.concatenate(xd, -1), np.concatenate(enc.recon_head(enc.feature_p)[0], -1))
+
+
 def test_mfma_model_matches_hardware_measurements(golden_dir):
     """The oracle's contraction arithmetic against v_mfma_f32_32x32x16_f16 outputs recorded on an
     MI355X (tools/mfma_probe2.hip): every trial bit-exact."""
