@@ -106,6 +106,31 @@ int dcvc_mul_channel(const void* x, int ldx, const void* q, void* y, int ldy, in
     return dcvc::guarded([&] { dcvc::mul_channel(H(x), ldx, H(q), H(y), ldy, pixels, C, S(stream)); });
 }
 
+int dcvc_scale_clamped(const void* x, int ldx, const void* q, int ldq, void* y, int ldy, int pixels,
+                       int C, int reciprocal, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::scale_clamped(H(x), ldx, H(q), ldq, H(y), ldy, pixels, C, reciprocal != 0, S(stream));
+    });
+}
+
+int dcvc_yuv420_to_x(const void* y, const void* uv, int H_, int W_, void* x, int ldx, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::yuv420_to_x(static_cast<const uint8_t*>(y), static_cast<const uint8_t*>(uv), H_, W_, H(x), ldx,
+                          S(stream));
+    });
+}
+
+int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H_, int W_, void* y16, void* uv16, void* y8,
+                     void* uv8, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::x_to_yuv420(H(x_hat), row_pixels, H_, W_, H(y16), H(uv16), static_cast<uint8_t*>(y8),
+                          static_cast<uint8_t*>(uv8), S(stream));
+    });
+}
+
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream)
 {
     return dcvc::guarded([&] {

@@ -102,6 +102,17 @@ void mul_channel(const half_t* x, int ldx, const half_t* q, half_t* y, int ldy, 
 void scale_clamped(const half_t* x, int ldx, const half_t* q, int ldq, half_t* y, int ldy, int pixels,
                    int C, bool reciprocal, hipStream_t stream);
 
+// ---------------------------------------------------------------- picture I/O (frame_io.hip)
+// 8-bit YUV420 planes (y [H][W], uv [2][H/2][W/2]) -> x fp16, 3 channels per pixel at pixel
+// stride ldx (3 for one picture, 24 + a channel offset for a chunk of 8): nearest-neighbour
+// chroma, x = fp16(fp16(v / 255) - 0.5)   (test_video.py:69-123, transforms.py:69-80)
+void yuv420_to_x(const uint8_t* y, const uint8_t* uv, int H, int W, half_t* x, int ldx, hipStream_t stream);
+// x_hat fp16 [rows][row_pixels][3] -> the top-left H x W picture as YUV420: fp16 planes scaled to
+// 0..255 (what get_distortion measures, test_video.py:32-45) and / or u8 planes (what the writer
+// stores, test_video.py:356-363: Y rounded half-to-even, U/V truncated). Null outputs are skipped.
+void x_to_yuv420(const half_t* x, int row_pixels, int H, int W, half_t* y16, half_t* uv16, uint8_t* y8,
+                 uint8_t* uv8, hipStream_t stream);
+
 // ---------------------------------------------------------------- symbol kernels (symbols.hip)
 // Uploads the scale -> Gaussian-table-index lookup table (call once per process before the
 // first symbol kernel and outside any graph capture).

@@ -1,0 +1,91 @@
+"""Multi-GPU sharding of a coding job: one process per GPU, independent units per rank, no
+data-path collective.
+
+What is independent in DCVC-UF:
+  * intra coding: every picture;
+  * inter coding: every intra period (a GOP starts from an I picture and re-seeds the temporal
+    state with add_ref_feature_from_frame - test_video.py:206-231), and inside a GOP nothing: picture
+    t needs the feature memory of picture t-1, so a GOP stays on one GPU;
+  * rate sweeps: every qp (the reference's own scaling mode, test_video.py:530-560 worker pool).
+The only communication is the control plane: rank 0 collects the coded units (bytes) in display
+order. With backend "nccl" (= RCCL) the byte payloads travel as uint8 device tensors over xGMI,
+with "gloo" (CPU tests) as host tensors.
+"""
+import numpy as np
+import torch
+
+
+def shard_range(n_units, rank, world):
+    """Contiguous balanced split: the first (n_units % world) ranks get one extra unit."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError("bad rank/world")
+    base, extra = divmod(n_units, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def plan_gops(frame_num, intra_period, frame_delay=1):
+    """Independent units of an inter-coded sequence as (first_frame, n_frames), following the
+    I-picture placement of test_video.py:204-213: frame 0 is intra; with intra_period > 1 every
+    frame with index % intra_period == 1 (other than frame 1) starts a new GOP; intra_period
+    <= 0 means one GOP; intra_period == 1 means all-intra."""
+    if frame_num <= 0:
+        return []
+    if intra_period == 1:
+        return [(i, 1) for i in range(frame_num)]
+    if intra_period > 1 and intra_period % frame_delay != 0:
+        raise ValueError("intra_period must be a multiple of the model's frame delay")
+    starts = [0]
+    if intra_period > 1:
+        starts += [i for i in range(2, frame_num) if i % intra_period == 1]
+    return [(s, e - s) for s, e in zip(starts, starts[1:] + [frame_num])]
+
+
+def _device_for(dist):
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def gather_units(local_units, dist=None, dst=0):
+    """local_units: list of (unit_index, bytes) coded by this rank. Returns on rank `dst` the list
+    of bytes of ALL ranks ordered by unit_index (None elsewhere). Two collectives: one all_gather
+    of the (index, length) table, one all_gather of the padded payloads."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [b for _, b in sorted(local_units, key=lambda u: u[0])]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _device_for(dist)
+    count = torch.tensor([len(local_units)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    max_units = max(int(c.item()) for c in counts)
+    table = torch.full((max(max_units, 1), 2), -1, dtype=torch.int64, device=dev)
+    for i, (idx, b) in enumerate(local_units):
+        table[i, 0], table[i, 1] = idx, len(b)
+    tables = [torch.zeros_like(table) for _ in range(world)]
+    dist.all_gather(tables, table)
+    totals = [int(t[:, 1].clamp(min=0).sum().item()) for t in tables]
+    cap = max(max(totals), 1)
+    payload = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    mine = b"".join(b for _, b in local_units)
+    if mine:
+        payload[:len(mine)] = torch.from_numpy(np.frombuffer(mine, dtype=np.uint8).copy()).to(dev)
+    payloads = [torch.zeros_like(payload) for _ in range(world)]
+    dist.all_gather(payloads, payload)
+    if rank != dst:
+        return None
+    units = []
+    for t, p in zip(tables, payloads):
+        host, off = p.cpu().numpy(), 0
+        for idx, n in t.cpu().tolist():
+            if idx < 0:
+                continue
+            units.append((idx, host[off:off + n].tobytes()))
+            off += n
+    return [b for _, b in sorted(units, key=lambda u: u[0])]
+
+
+def code_sharded(n_units, code_unit, dist=None):
+    """Runs code_unit(unit_index) -> bytes for this rank's share and gathers everything on rank 0."""
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    local = [(i, code_unit(i)) for i in shard_range(n_units, rank, world)]
+    return gather_units(local, dist)

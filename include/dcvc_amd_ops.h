@@ -55,6 +55,22 @@ int dcvc_crop(const void* in, int ldin, int Win, void* out, int ldout, int H, in
 int dcvc_mul_channel(const void* x, int ldx, const void* q, void* y, int ldy, int pixels, int C,
                      void* stream);
 
+/* stream.cu:40-76 / 422-443: y = x * max(q, 0.5) or, with reciprocal != 0, y = x * fp16(1 / max(q, 0.5));
+ * q is a tensor of the same shape (the inter models' per-element quantisation step). */
+int dcvc_scale_clamped(const void* x, int ldx, const void* q, int ldq, void* y, int ldy, int pixels,
+                       int C, int reciprocal, void* stream);
+
+/* Picture I/O on the device, replacing the host-side numpy/scipy/torch chains of the harness.
+ * test_video.py:69-123 get_src_frame (+ transforms.py:69-80 ycbcr420_to_444_np, order 0):
+ *   y: u8 [H][W], uv: u8 [2][H/2][W/2] (device) -> x fp16 at pixel stride ldx (3 channels written):
+ *   nearest chroma, x = fp16(fp16(v / 255) - 0.5). */
+int dcvc_yuv420_to_x(const void* y, const void* uv, int H, int W, void* x, int ldx, void* stream);
+/* test_video.py:32-45 get_distortion and :356-363 (decoded-picture writer):
+ *   x_hat fp16 [rows][row_pixels][3] -> top-left H x W picture; y16/uv16: fp16 planes in 0..255,
+ *   y8/uv8: u8 planes (Y rounded half-to-even, U/V truncated as the reference does). Null = skip. */
+int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H, int W, void* y16, void* uv16, void* y8,
+                     void* uv8, void* stream);
+
 /* def_elementwise.h: round_z_cuda / int8_to_dtype_cuda */
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream);
 int dcvc_int8_to_half(const void* in, void* out, int count, void* stream);

@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard a coding job and rank 0 collects the coded
+units in order (dcvc_amd/sharding.py). The per-unit coder is a stand-in (the codec itself has no
+CPU path); what is under test is the unit assignment and the collection collectives."""
+import hashlib
+import os
+import pickle
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from dcvc_amd import sharding
+
+
+def test_shard_range_covers_everything_once():
+    for n in (0, 1, 7, 8, 33):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in sharding.shard_range(n, r, world)]
+            assert got == list(range(n))
+            sizes = [len(sharding.shard_range(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_plan_gops_follows_reference_intra_placement():
+    assert sharding.plan_gops(5, 1) == [(i, 1) for i in range(5)]
+    assert sharding.plan_gops(97, -1, 8) == [(0, 97)]
+    # test_video.py:204-213: I pictures at 0 and at every index % 32 == 1 except index 1
+    assert sharding.plan_gops(100, 32) == [(0, 33), (33, 32), (65, 32), (97, 3)]
+    with pytest.raises(ValueError):
+        sharding.plan_gops(100, 12, 8)
+
+
+def _fake_code(i):
+    return hashlib.sha256(b"unit %d" % i).digest() * (1 + i % 5) if i % 4 else b""
+
+
+def _worker(rank, world, port, n_units, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = sharding.code_sharded(n_units, _fake_code, dist)
+        if rank == 0:
+            with open(out_path, 'wb') as f:
+                pickle.dump(res, f)
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_units", [7, 1])
+def test_two_ranks_collect_units_in_order(tmp_path, n_units):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "units.pt")
+    mp.spawn(_worker, args=(2, port, n_units, out), nprocs=2, join=True)
+    with open(out, 'rb') as f:
+        got = pickle.load(f)
+    assert got == [_fake_code(i) for i in range(n_units)]
+
+
+def test_single_process_path():
+    assert sharding.code_sharded(5, _fake_code) == [_fake_code(i) for i in range(5)]
