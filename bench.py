@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""bench.py - DCVC-UF-Intra 1080p YUV420 encode+decode throughput on MI355X.
+"""bench.py - DCVC-UF 1080p YUV420 encode+decode throughput on MI355X (default: DCVC-UF-Intra).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
@@ -47,7 +47,17 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--frames", type=int, default=5, help="distinct synthetic pictures per rank")
+    p.add_argument("--workload", default="intra", choices=("intra", "ld", "hts", "htl"),
+                   help="intra = the headline configuration (BASELINE.json configs[1]); ld / hts / htl = the inter "
+                        "models of configs[2] (one step = one call: 1 picture for ld, a chunk of 8 for hts / htl)")
     return p.parse_args()
+
+
+def _to_gpu(net, device):
+    import copy
+    g = copy.deepcopy(net).half().to(device)       # finalize_model, test_video.py:27-29
+    g.proxy = None
+    return g
 
 
 def build_model(device):
@@ -55,11 +65,7 @@ def build_model(device):
     net = models.DMCI()
     net.load_state_dict(synthetic.synthetic_state_dict(arch.dmci_spec(), 0))
     net.update(SKIP_THRES)
-    cpu_net = net
-    import copy
-    gpu_net = copy.deepcopy(net).half().to(device)
-    gpu_net.proxy = None
-    return cpu_net, gpu_net
+    return net, _to_gpu(net, device)
 
 
 def make_pictures(n, rank, device):
@@ -76,6 +82,65 @@ def step(net, x, qp, pad_b, pad_r):
     enc = net.compress(x, qp, pad_b, pad_r)
     dec = net.decompress(enc["bit_stream"], {"height": HEIGHT, "width": WIDTH}, qp, enc["ec_parallel"])
     return enc, dec
+
+
+class InterWorkload:
+    """configs[2]: P pictures with the inter models. One step = one compress + one decompress call
+    (separate encoder / decoder objects, the decoder sees only the bytes): 1 picture for LD, a chunk
+    of 8 for HT-S / HT-L. Every `gop` steps both sides are re-seeded from an intra reconstruction
+    (add_ref_feature_from_frame; the I picture itself is coded outside the timed region), LD resets
+    its feature memory every 32 pictures like the reference default (test_video.py:148,232)."""
+
+    def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r):
+        from dcvc_amd import arch, models, synthetic
+        self.kind, self.pics, self.pad_b, self.pad_r = kind, pics, pad_b, pad_r
+        if kind == "ld":
+            net = models.DMC()
+            net.load_state_dict(synthetic.synthetic_state_dict(arch.dmc_ld_spec(), 0))
+            self.frames, self.gop = 1, 96
+        else:
+            net = models.DMCHT(kind)
+            net.load_state_dict(synthetic.synthetic_state_dict(arch.dmc_ht_spec(kind == "hts"), 0))
+            self.frames, self.gop = 8, 12
+        net.update(SKIP_THRES)
+        self.enc, self.dec = _to_gpu(net, device), _to_gpu(net, device)
+        ref = gpu_intra.compress(pics[0], 32, pad_b, pad_r)["x_hat"]
+        self.ref = ref.clone()
+        if self.frames == 1:
+            self.inputs = pics
+        else:
+            self.inputs = [torch.cat([pics[(i + j) % len(pics)] for j in range(8)], dim=1).contiguous(
+                memory_format=torch.channels_last) for i in range(len(pics))]
+        self.proxies = lambda: (self.enc.proxy, self.dec.proxy)
+
+    def step(self, i, qp):
+        if i % self.gop == 0:
+            self.enc.add_ref_feature_from_frame(self.ref)
+            self.dec.add_ref_feature_from_frame(self.ref, apply_feature_adaptor=False)
+        # picture index inside the GOP (0 = the I picture); (frame_idx + g_frame_delay) % reset_interval == 1
+        reset = 1 if (self.frames == 1 and (i % self.gop + 1) % 32 == 0) else 0
+        x = self.inputs[i % len(self.inputs)]
+        enc = self.enc.compress(x, qp, reset, self.pad_b, self.pad_r)
+        self.dec.decompress(enc["bit_stream"], {"height": HEIGHT, "width": WIDTH}, qp, enc["ec_parallel"], reset)
+        return len(enc["bit_stream"])
+
+    def set_use_graphs(self, on):
+        for g in (self.enc, self.dec):
+            g._ensure_proxy().set_use_graphs(on)
+
+
+class IntraWorkload:
+    frames, kind = 1, "intra"
+
+    def __init__(self, gpu_net, pics, pad_b, pad_r):
+        self.net, self.pics, self.pad_b, self.pad_r = gpu_net, pics, pad_b, pad_r
+
+    def step(self, i, qp):
+        enc, _ = step(self.net, self.pics[i % len(self.pics)], qp, self.pad_b, self.pad_r)
+        return len(enc["bit_stream"])
+
+    def set_use_graphs(self, on):
+        self.net._ensure_proxy().set_use_graphs(on)
 
 
 def cpu_baseline(cpu_net):
@@ -98,22 +163,22 @@ def cpu_baseline(cpu_net):
     }
 
 
-def roofline(gpu_net, pics, pad_b, pad_r):
-    """conv_gemm launches of encode+decode bracketed by HIP events (eager pass)."""
+def roofline(work):
+    """conv_gemm launches of the workload's steps bracketed by HIP events (eager pass)."""
     from dcvc_amd import _lib
     en = _lib.fn("dcvc_gemm_profile_enable", ctypes.c_int, [ctypes.c_int])
     rs = _lib.fn("dcvc_gemm_profile_reset", ctypes.c_int, [])
     co = _lib.fn("dcvc_gemm_profile_collect", ctypes.c_int,
                  [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                   ctypes.POINTER(ctypes.c_longlong)])
-    gpu_net.proxy.set_use_graphs(False)
-    step(gpu_net, pics[0], QPS[2], pad_b, pad_r)      # eager warm-up
+    work.set_use_graphs(False)
+    work.step(1, QPS[2])                                 # eager warm-up
     torch.cuda.synchronize()
     _lib.check(en(1))
     _lib.check(rs())
     n = 0
     for i, qp in enumerate(QPS):
-        step(gpu_net, pics[i % len(pics)], qp, pad_b, pad_r)
+        work.step(2 + i, qp)
         n += 1
     torch.cuda.synchronize()
     ms, fl, ln = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
@@ -135,11 +200,21 @@ def roofline(gpu_net, pics, pad_b, pad_r):
                 f.write("%d,%d,%d,%d,%.1f,%.2f,%.1f,%.3f\n" % (
                     k + (a[0] / n, 1e3 * a[1] / a[0], 2.0 * k[0] * k[1] * k[2] / (a[1] / a[0] * 1e-3) / 1e12, a[1] / n)))
     _lib.check(en(0))
-    gpu_net.proxy.set_use_graphs(True)
+    work.set_use_graphs(True)
     achieved = fl.value / (ms.value * 1e-3) / 1e12
+    # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the
+    # rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE average over the conv_gemm launches
+    # of this same command, collected by tools/pmc_session.sh and committed under profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            traffic = json.load(f)["kernels"]["conv_gemm"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "bound": "mfma", "kernel": "conv_gemm_kernel", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+        "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": None,
         "launches_per_step": ln.value / n, "avg_launch_us": ms.value * 1e3 / ln.value,
         "gflop_per_step": fl.value / n / 1e9, "gemm_ms_per_step": ms.value / n,
     }
@@ -167,28 +242,25 @@ def main():
     cpu_net, gpu_net = build_model(device)
     pics = make_pictures(args.frames, rank, device)
     pad_r, pad_b = gpu_net.get_padding_size(HEIGHT, WIDTH, 16)
+    if args.workload == "intra":
+        work = IntraWorkload(gpu_net, pics, pad_b, pad_r)
+    else:
+        work = InterWorkload(args.workload, device, pics, gpu_net, pad_b, pad_r)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("DCVC_BENCH_EAGER"):          # experiment: eager launches instead of hipGraph replay
+        work.set_use_graphs(False)
     for i in range(args.warmup):
-        step(gpu_net, pics[i % len(pics)], QPS[i % len(QPS)], pad_b, pad_r)
+        work.step(i, QPS[i % len(QPS)])
     sync()
-    t_enc = t_dec = 0.0
     nbytes = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        x, qp = pics[i % len(pics)], QPS[i % len(QPS)]
-        a = time.perf_counter()
-        enc = gpu_net.compress(x, qp, pad_b, pad_r)
-        b = time.perf_counter()
-        gpu_net.decompress(enc["bit_stream"], {"height": HEIGHT, "width": WIDTH}, qp, enc["ec_parallel"])
-        c = time.perf_counter()
-        t_enc += b - a
-        t_dec += c - b
-        nbytes += len(enc["bit_stream"])
+        nbytes += work.step(args.warmup + i, QPS[i % len(QPS)])
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -197,26 +269,27 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        names = {"intra": "DCVC-UF-Intra (DMCI)", "ld": "DCVC-UF inter LD (DMC low-delay)",
+                 "hts": "DCVC-UF inter HT-S (8-picture chunks)", "htl": "DCVC-UF inter HT-L (8-picture chunks)"}
+        fps = world * args.steps * work.frames / elapsed
         out = {
-            "metric": "1080p YUV420 intra encode+decode pictures per second (DCVC-UF-Intra, real rANS "
-                      "bit streams, q_index in {0,16,32,48,63})",
-            "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
+            "metric": "1080p YUV420 %s encode+decode pictures per second (%s, real rANS bit streams, "
+                      "q_index in {0,16,32,48,63})" % ("intra" if args.workload == "intra" else "inter", names[args.workload]),
+            "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the "
-                    "reference DMCI architecture)",
-            "config": {"workload": "DCVC-UF-Intra 1080p YUV420 on 1xMI355X per rank, q_index cycling "
-                                   "{0,16,32,48,63}, skip_thres 0.15, one picture per step: compress + decompress",
-                       "pictures_per_step": 1, "resolution": "%dx%d" % (WIDTH, HEIGHT)},
-            # host-side split of one step (the decode of step i cannot overlap its own encode);
-            # compress() returns when the bit stream is ready, its reconstruction may still be running
-            "encode_fps_host_view": args.steps / t_enc, "decode_fps_host_view": args.steps / t_dec,
-            "bytes_per_picture": nbytes / args.steps,
-            "bpp": 8.0 * nbytes / args.steps / (HEIGHT * WIDTH),
+                    "reference architecture)",
+            "config": {"workload": "%s 1080p YUV420 on 1xMI355X per rank, q_index cycling {0,16,32,48,63}, "
+                                   "skip_thres 0.15, one step = compress + decompress of %d picture(s)"
+                                   % (names[args.workload], work.frames),
+                       "pictures_per_step": work.frames, "resolution": "%dx%d" % (WIDTH, HEIGHT)},
+            "bytes_per_picture": nbytes / args.steps / work.frames,
+            "bpp": 8.0 * nbytes / args.steps / work.frames / (HEIGHT * WIDTH),
         }
         if not args.no_roofline:
-            out["roofline"] = roofline(gpu_net, pics, pad_b, pad_r)
-        if not args.no_cpu_baseline:
+            out["roofline"] = roofline(work)
+        if not args.no_cpu_baseline and args.workload == "intra":
             out["cpu_baseline"] = cpu_baseline(cpu_net)
         print(json.dumps(out), flush=True)
     if dist is not None:

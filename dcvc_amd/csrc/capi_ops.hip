@@ -131,6 +131,11 @@ int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H_, int W_, void* y1
     });
 }
 
+int dcvc_gemm_timeline_buffer(void* device_buffer)
+{
+    return dcvc::guarded([&] { dcvc::gemm_timeline_buffer(static_cast<long long*>(device_buffer)); });
+}
+
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream)
 {
     return dcvc::guarded([&] {

@@ -1,6 +1,10 @@
 // See codec_base.h.
 #include "codec/codec_base.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace dcvc {
 
 CodecBase::CodecBase()
@@ -106,10 +110,16 @@ void CodecBase::worker_loop()
             job = std::move(m_job);
         }
         std::string err;
+        static const bool trace = getenv("DCVC_TIMING") != nullptr;      // tuning aid: job time to stderr
+        const auto t0 = std::chrono::steady_clock::now();
         try {
             job();
         } catch (const std::exception& e) {
             err = e.what();
+        }
+        if (trace) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "[dcvc] entropy job %.0f us, %zu bytes\n", us, m_enc.stream().size());
         }
         {
             std::lock_guard<std::mutex> lk(m_mu);

@@ -5,6 +5,9 @@
 #include "codec/dmc_ld.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace dcvc {
 
@@ -17,6 +20,10 @@ enum StageKey : int { kRef = 0, kEnc0 = 1, kEnc1 = 2 /* +reset */, kDec0 = 10 /*
 
 DmcLdCodec::DmcLdCodec()
 {
+    // LD's kernels are short (4.2 ms of kernel time in ~350 launches per 1080p picture): measured on
+    // MI355X, eager launches on the codec's stream beat hipGraph replay (139 vs 123 pictures/s), the
+    // other codecs are neutral. set_use_graphs(true) switches back.
+    m_use_graphs = false;
     hip_check(hipEventCreateWithFlags(&m_ev_idx, hipEventDisableTiming), "hipEventCreate");
 }
 
@@ -325,6 +332,14 @@ int DmcLdCodec::compress(const half_t* x, int height, int width, int qp, bool re
 
 void DmcLdCodec::entropy_encode(int qp)
 {
+    static const bool trace = getenv("DCVC_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (trace) {
+            fprintf(stderr, "[dcvc]   ld encode: %s at +%.0f us\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+    };
     // dmc_ld_proxy.cpp worker, Encode: y symbols then z
     const Geometry& g = m_g;
     hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, sizeof(int32_t), hipMemcpyDeviceToHost, m_io_stream), "D2H totals");
@@ -332,16 +347,19 @@ void DmcLdCodec::entropy_encode(int qp)
     hip_check(hipMemcpyAsync(m_h_z.get(), m_ZI8, nz, hipMemcpyDeviceToHost, m_io_stream), "D2H z");
     hip_check(hipStreamSynchronize(m_io_stream), "sync io");
     const int total = m_h_totals[0];
+    lap("totals + z on the host (GPU stage 0 done)");
     if (total > 0) {
         hip_check(hipMemcpyAsync(m_h_sym.get(), m_COMP, static_cast<size_t>(total) * 2, hipMemcpyDeviceToHost, m_io_stream), "D2H symbols");
         hip_check(hipStreamSynchronize(m_io_stream), "sync io");
     }
+    lap("symbols on the host");
     m_ec_parallel = ec_parallel_for(total);
     m_enc.reset();
     m_enc.set_parallel(m_ec_parallel);
     m_enc.push_y(m_h_sym.get(), total);
     m_enc.push_z(m_h_z.get(), nz, qp * kChZ, kChZ);
     m_enc.flush();
+    lap("rANS done");
 }
 
 // ------------------------------------------------------------------------------------ decompress

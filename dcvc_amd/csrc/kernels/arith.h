@@ -26,13 +26,17 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 // result), evaluated with exactly-rounded operations only (fmaf, floor, min/max) so that the CPU
 // oracle reproduces it bit for bit. It replaces an exp + IEEE-division formulation that cost
 // ~30 VALU operations per element - more than the matrix-core time of the 4x expanded FFN tile.
-// `tab` points to the 4 KiB coefficient table (kernels/wsilu_table.h) in LDS.
+// `tab` points to the coefficient table (kernels/wsilu_table.h) in LDS, entry e at tab[e * R]:
+// R = 1 is the plain 4 KiB table; the contraction kernel's epilogue uses R interleaved copies
+// with every lane reading "its own" copy (tab already offset by lane & (R - 1)), which puts the 16
+// lanes of a ds_read_b128 group on 16 different 16-byte bank slots whatever entries they ask for.
+template <int R = 1>
 __device__ __forceinline__ float wsilu_spec(float v, const float4* tab)
 {
     float t = fmaf(v, 16.0f, 128.0f);
     t = fminf(fmaxf(t, 0.0f), 255.99998f);
     const float f = __builtin_amdgcn_fractf(t);      // t - floor(t), exact
-    const float4 c = tab[static_cast<int>(t)];        // t >= 0: truncation == floor
+    const float4 c = tab[static_cast<int>(t) * R];    // t >= 0: truncation == floor
     float p = fmaf(c.w, f, c.z);
     p = fmaf(p, f, c.y);
     p = fmaf(p, f, c.x);
@@ -41,6 +45,7 @@ __device__ __forceinline__ float wsilu_spec(float v, const float4* tab)
 
 // Batched forms: all table indices first, then all LDS reads, then the polynomials - the loads
 // overlap instead of exposing one LDS round trip per element.
+template <int R = 1>
 __device__ __forceinline__ void wsilu8(float (&v)[8], const float4* tab)
 {
     float f[8];
@@ -50,7 +55,7 @@ __device__ __forceinline__ void wsilu8(float (&v)[8], const float4* tab)
         float t = fmaf(v[e], 16.0f, 128.0f);
         t = fminf(fmaxf(t, 0.0f), 255.99998f);
         f[e] = __builtin_amdgcn_fractf(t);
-        c[e] = tab[static_cast<int>(t)];
+        c[e] = tab[static_cast<int>(t) * R];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -61,6 +66,7 @@ __device__ __forceinline__ void wsilu8(float (&v)[8], const float4* tab)
     }
 }
 
+template <int R = 1>
 __device__ __forceinline__ void wsilu16(const float16v& a, float (&z)[16], const float4* tab)
 {
 #pragma unroll
@@ -68,7 +74,7 @@ __device__ __forceinline__ void wsilu16(const float16v& a, float (&z)[16], const
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = a[8 * h + e];
-        wsilu8(v, tab);
+        wsilu8<R>(v, tab);
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[8 * h + e] = v[e];
     }

@@ -73,6 +73,7 @@ struct ConvGemmParams {
     int in_h, in_w, out_h, out_w;   // input / output grid
     int cin, ksize, stride, pad;
     int up_dy, up_dx;               // transposed conv: this launch writes pixel (2y+dy, 2x+dx)
+    long long* timeline;            // optional [blocks][16] shader-clock stamps of wave 0 (tools/gemm_timeline.py)
 };
 
 enum : int { ACT_NONE = 0, ACT_WSILU = 1 };
@@ -123,6 +124,14 @@ conv_gemm_kernel(const ConvGemmParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int stamp_no = 0;
+    auto stamp = [&]() {
+        if (p.timeline != nullptr && tid == 0 && stamp_no < 16) {
+            p.timeline[static_cast<size_t>(blockIdx.x) * 16 + stamp_no] = static_cast<long long>(__builtin_readcyclecounter());
+        }
+        ++stamp_no;
+    };
+    stamp();                                                       // 0: kernel entry
     const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5;
 
@@ -151,16 +160,22 @@ conv_gemm_kernel(const ConvGemmParams p)
     for (int j = 0; j < WU; ++j)
         wsrc[j] = p.w + static_cast<size_t>(min(n0 + j * ROWS_PER_PASS + srow, p.N - 1)) * p.K + schunk * 8;
 
-    auto stage = [&](int buf, int k0) {
+    // part < 0: the whole tile; part = 0..3: the share of k-slice `part` (the main loop spreads the
+    // next tile's loads over the four slices of the current one: a global_load_lds costs the
+    // issuing wave ~100 cycles, eight of them in a row at the top of a k-step left the matrix
+    // pipe idle for a third of the step)
+    auto stage = [&](int buf, int k0, int part) {
         char* xs = smem + buf * STAGE_BYTES;
         char* ws = xs + XT_BYTES;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
+            if (part >= 0 && (j < 3 ? j : 3) != part) continue;
             const half_t* xsrc = x_row_ptr<SPATIAL>(p, xrow[j], k0) + schunk * 8;
             __builtin_amdgcn_global_load_lds((gptr_t)xsrc, (lptr_t)(xs + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < WU; ++j) {
+            if (part >= 0 && (j < 3 ? j : 3) != part) continue;
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(ws + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
         }
     };
@@ -174,6 +189,12 @@ conv_gemm_kernel(const ConvGemmParams p)
 
     const bool wave_active = (n0 + wn * (NT * 32)) < p.N;   // N is a multiple of NT*32 per wave
     const int nk = p.K / BK;
+
+    // the first tile goes out before anything else touches the memory pipeline
+    stage(0, 0, -1);
+    if constexpr (STAGES == 3) {
+        if (nk > 1) stage(1, BK, -1);
+    }
 
     // The accumulators start at the bias (arithmetic policy: y = ((bias + p_0) + p_1) + ...), so
     // the epilogue has no bias traffic at all. acc[nt][mt][r] belongs to channel
@@ -197,22 +218,22 @@ conv_gemm_kernel(const ConvGemmParams p)
         for (int b = 0; b < MT; ++b) acc[a][b] = init;
     }
 
-    // first residual: whole rows, 16 B per lane, consumed after the main loop
+    // first residual: whole rows, 16 B per lane, consumed after the main loop. The loads are
+    // issued inside the main loop (first k-step) so that they are neither in front of the first
+    // tile in the memory pipeline nor drained by the first barrier's vmcnt(0).
     half8 rpre[NRES >= 1 ? OUNITS : 1];
-    if constexpr (NRES >= 1) {
+    auto load_residual = [&]() {
+        if constexpr (NRES >= 1) {
 #pragma unroll
-        for (int j = 0; j < OUNITS; ++j) {
-            const int u = j * NTHREADS + tid;
-            const int row = min(m0 + u / OCH, p.M - 1);
-            const int ch = min(n0 + (u % OCH) * 8, p.N - 8);
-            rpre[j] = *reinterpret_cast<const half8*>(p.r1 + static_cast<size_t>(row) * p.ldr1 + ch);
+            for (int j = 0; j < OUNITS; ++j) {
+                const int u = j * NTHREADS + tid;
+                const int row = min(m0 + u / OCH, p.M - 1);
+                const int ch = min(n0 + (u % OCH) * 8, p.N - 8);
+                rpre[j] = *reinterpret_cast<const half8*>(p.r1 + static_cast<size_t>(row) * p.ldr1 + ch);
+            }
         }
-    }
+    };
 
-    stage(0, 0);
-    if constexpr (STAGES == 3) {
-        if (nk > 1) stage(1, BK);
-    }
     const float4* tab = nullptr;
     if constexpr (ACT == ACT_WSILU) {
         // WSiLU coefficient table -> LDS (behind the stages); visible after the first barrier
@@ -220,11 +241,14 @@ conv_gemm_kernel(const ConvGemmParams p)
         for (int i = tid; i < WSILU_SEGMENTS; i += NTHREADS) t[i] = p.wsilu[i];
         tab = t;
     }
+    if constexpr (STAGES == 3) load_residual();     // (tuning variant only: waited for with tile 0)
+    stamp();                                                       // 1: prologue issued
     for (int t = 0; t < nk; ++t) {
         int cur;
         if constexpr (STAGES == 2) {
             __syncthreads();             // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
-            if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+            if (t < 8) stamp();                                    // 2..9: k-step t may start
+            if (t == 0) load_residual();
             cur = t & 1;
         } else {
             // Two tiles in flight: wait only for the OLDER one (counted vmcnt), keep the younger
@@ -240,7 +264,7 @@ conv_gemm_kernel(const ConvGemmParams p)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             cur = t % 3;
-            if (t + 2 < nk) stage((t + 2) % 3, (t + 2) * BK);
+            if (t + 2 < nk) stage((t + 2) % 3, (t + 2) * BK, -1);
         }
         const char* xs = smem + cur * STAGE_BYTES + wm * (MT * 32 * 128);
         const char* ws = smem + cur * STAGE_BYTES + XT_BYTES + wn * (NT * 32 * 128);
@@ -267,7 +291,12 @@ conv_gemm_kernel(const ConvGemmParams p)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], xf[s & 1][mt], acc[nt][mt], 0, 0, 0);
+                if constexpr (STAGES == 2) {
+                    if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK, s);
+                }
             }
+        } else if constexpr (STAGES == 2) {
+            if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK, -1);
         }
     }
 
@@ -278,11 +307,31 @@ conv_gemm_kernel(const ConvGemmParams p)
     // lane and were 2/3 of the kernel time. The first residual arrives the same way (prefetched
     // row-wise into registers at kernel start, parked in the LDS tile here).
     __syncthreads();                                   // every wave is done with the stage buffers
+    stamp_no = 10;
+    stamp();                                                       // 10: main loop done
     char* otile = smem;
     constexpr int SWZ = OCH >= 8 ? 7 : OCH - 1;        // rows narrower than 128 B swizzle inside the row
     auto oaddr = [&](int row, int cidx) {              // 16-B chunk cidx of tile row `row`, bank swizzled
         return otile + row * (BNO * 2) + (((cidx & ~SWZ) | ((cidx & SWZ) ^ (row & SWZ))) << 4);
     };
+    // WSiLU table gathers are the epilogue's LDS hot spot (128 random 16-byte reads per lane and
+    // tile; measured 39 % of all LDS cycles lost to bank conflicts on the plain table). The dead
+    // stage area behind the output tile takes R interleaved copies so that lane l reads copy
+    // l & (R-1): conflict-free for R = 16, at most 16/R lanes per slot otherwise.
+    constexpr int OT_BYTES = BM * BNO * 2;
+    constexpr int AREA = STAGES * STAGE_BYTES;
+    constexpr int R = (ACT != ACT_WSILU) ? 1
+                    : (OT_BYTES + 16 * WSILU_TABLE_BYTES <= AREA) ? 16
+                    : (OT_BYTES + 8 * WSILU_TABLE_BYTES <= AREA) ? 8
+                    : (OT_BYTES + 4 * WSILU_TABLE_BYTES <= AREA) ? 4
+                    : (OT_BYTES + 2 * WSILU_TABLE_BYTES <= AREA) ? 2 : 1;
+    if constexpr (R > 1) {
+        float4* rep = reinterpret_cast<float4*>(smem + AREA - R * WSILU_TABLE_BYTES);
+        const float4* base = reinterpret_cast<const float4*>(smem + AREA);
+        for (int i = tid; i < R * WSILU_SEGMENTS; i += NTHREADS) rep[i] = base[i / R];
+        __syncthreads();
+        tab = rep + (lane & (R - 1));
+    }
     if constexpr (NRES >= 1) {
 #pragma unroll
         for (int j = 0; j < OUNITS; ++j) {
@@ -307,7 +356,7 @@ conv_gemm_kernel(const ConvGemmParams p)
                         const int nt = 2 * np + h;
                         float z[16];
                         if constexpr (ACT == ACT_WSILU) {
-                            wsilu16(acc[nt][mt], z, tab);
+                            wsilu16<R>(acc[nt][mt], z, tab);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 16; ++e) z[e] = acc[nt][mt][e];
@@ -343,7 +392,7 @@ conv_gemm_kernel(const ConvGemmParams p)
                         // this lane now holds channels cb .. cb+7 of pixel m
                         const int ct = ntile + nt * 32 + 16 * pr + 8 * hi;     // inside the tile
                         const int cb = n0 + ct;
-                        if constexpr (ACT == ACT_WSILU) wsilu8(v, tab);
+                        if constexpr (ACT == ACT_WSILU) wsilu8<R>(v, tab);
                         half8* slot = reinterpret_cast<half8*>(oaddr(row, ct >> 3));
                         if constexpr (NRES >= 1) {
                             const half8 r8 = *slot;
@@ -375,6 +424,7 @@ conv_gemm_kernel(const ConvGemmParams p)
         }
     }
     __syncthreads();
+    stamp();                                                       // 11: epilogue math done, tile in LDS
     // ---- whole-line stores: consecutive lanes write consecutive 16-B chunks of one pixel row
     const int n0o = CHUNK ? (n0 >> 2) : n0;
     const int nout = CHUNK ? (p.N >> 2) : p.N;
@@ -395,7 +445,10 @@ conv_gemm_kernel(const ConvGemmParams p)
                 *reinterpret_cast<const half8*>(oaddr(row, ch));
         }
     }
+    stamp();                                                       // 12: stores issued
 }
+
+long long* g_timeline = nullptr;       // tools/gemm_timeline.py: device buffer for the in-kernel stamps
 
 // ---- WSiLU table in device memory (uploaded once, outside any capture)
 const float4* wsilu_table_device()
@@ -468,6 +521,7 @@ template <bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE
 void launch(ConvGemmParams p, hipStream_t stream)
 {
     p.wsilu = (ACT == ACT_WSILU) ? wsilu_table_device() : nullptr;
+    p.timeline = g_timeline;
     const long long tiles128 = static_cast<long long>((p.M + 127) / 128) * ((p.N + 127) / 128);
     const long long mt256 = (p.M + 255) / 256;
     static const int force = [] { const char* e = getenv("DCVC_GEMM_CFG"); return e ? atoi(e) : 0; }();
@@ -520,6 +574,11 @@ void kernels_init()
 {
     (void)wsilu_table_device();
     symbols_init();
+}
+
+void gemm_timeline_buffer(long long* device_buffer)
+{
+    g_timeline = device_buffer;
 }
 
 void gemm_profile_enable(bool on)

@@ -36,6 +36,10 @@ struct GemmLaunchInfo {
     float ms;
 };
 size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap);
+// Tuning aid: when non-null, wave 0 of every workgroup of the following contraction launches
+// writes up to 16 shader-clock stamps (kernel entry, prologue issued, start of k-steps 0..7, main
+// loop done, epilogue math done, stores issued) to buffer[block * 16 + i]. Null switches it off.
+void gemm_timeline_buffer(long long* device_buffer);
 
 // ---------------------------------------------------------------- dense convolutions (conv_gemm.hip)
 struct Conv1x1Desc {

@@ -71,6 +71,10 @@ int dcvc_yuv420_to_x(const void* y, const void* uv, int H, int W, void* x, int l
 int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H, int W, void* y16, void* uv16, void* y8,
                      void* uv8, void* stream);
 
+/* Tuning aid (no reference counterpart): device buffer of [blocks][16] int64 shader-clock stamps
+ * written by wave 0 of every workgroup of the following contraction launches; NULL = off. */
+int dcvc_gemm_timeline_buffer(void* device_buffer);
+
 /* def_elementwise.h: round_z_cuda / int8_to_dtype_cuda */
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream);
 int dcvc_int8_to_half(const void* in, void* out, int count, void* stream);
