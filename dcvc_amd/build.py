@@ -72,7 +72,8 @@ def _compile(src, obj, verbose):
 
 
 def _digest(paths):
-    h = hashlib.sha256(" ".join(COMMON + HIP_FLAGS).encode())
+    # flags with the checkout location factored out: the tree is copied to another path on the GPU box
+    h = hashlib.sha256(" ".join(COMMON + HIP_FLAGS).replace(ROOT, "<root>").encode())
     for p in sorted(paths):
         h.update(os.path.relpath(p, ROOT).encode())
         with open(p, "rb") as f:

@@ -534,6 +534,8 @@ void launch(ConvGemmParams p, hipStream_t stream)
         case 5: launch_cfg<2, 2, 1, 2, 3, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
         case 6: launch_cfg<2, 2, 1, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
         case 7: launch_cfg<4, 2, 2, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 8: launch_cfg<2, 2, 2, 4, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 9: launch_cfg<4, 1, 1, 4, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
         default: break;
         }
     }
