@@ -131,6 +131,56 @@ int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H_, int W_, void* y1
     });
 }
 
+int dcvc_mask_step_enc(void* y, int ldy, const void* q_dec, int ldq, const void* scales, int lds,
+                       const void* means, int ldm, void* y_hat, int ldh, void* sym, void* cond,
+                       void* block_count, void* compact_out, void* totals, int Hh, int W, int C,
+                       int nsteps, int step, float skip_thres, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::symbols_init();
+        dcvc::MaskStepEnc d;
+        d.y = H(y); d.ldy = ldy; d.q_dec = H(q_dec); d.ldq = ldq; d.scales = H(scales); d.lds = lds;
+        d.means = H(means); d.ldm = ldm; d.y_hat = H(y_hat); d.ldh = ldh;
+        d.sym = static_cast<int16_t*>(sym); d.cond = static_cast<uint8_t*>(cond);
+        d.block_count = static_cast<int32_t*>(block_count);
+        d.H = Hh; d.W = W; d.C = C; d.nsteps = nsteps; d.step = step; d.skip_thres = skip_thres;
+        dcvc::mask_step_enc(d, S(stream));
+        if (step == nsteps - 1) {
+            dcvc::compact(sym, 2, d.cond, d.block_count, Hh * W * C, compact_out, static_cast<int32_t*>(totals), 0,
+                          S(stream));
+        }
+    });
+}
+
+int dcvc_mask_dec_index(const void* scales, int lds, void* index, void* cond, void* block_count,
+                        void* compact_out, void* totals, int Hh, int W, int C, float skip_thres, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::symbols_init();
+        dcvc::MaskDecIndex d;
+        d.scales = H(scales); d.lds = lds; d.index = static_cast<uint8_t*>(index);
+        d.cond = static_cast<uint8_t*>(cond); d.block_count = static_cast<int32_t*>(block_count);
+        d.H = Hh; d.W = W; d.C = C; d.skip_thres = skip_thres;
+        dcvc::mask_dec_index(d, S(stream));
+        dcvc::compact(index, 1, d.cond, d.block_count, Hh * W * C, compact_out, static_cast<int32_t*>(totals), 0,
+                      S(stream));
+    });
+}
+
+int dcvc_mask_step_dec(const void* decoded, const void* cond, const void* block_count, const void* totals,
+                       void* yq, const void* means, int ldm, const void* q_dec, int ldq, void* y_hat, int ldh,
+                       int Hh, int W, int C, int nsteps, int step, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::MaskStepDec d;
+        d.decoded = static_cast<const int8_t*>(decoded); d.cond = static_cast<const uint8_t*>(cond);
+        d.block_count = static_cast<const int32_t*>(block_count); d.totals = static_cast<const int32_t*>(totals);
+        d.yq = static_cast<int8_t*>(yq); d.means = H(means); d.ldm = ldm; d.q_dec = H(q_dec); d.ldq = ldq;
+        d.y_hat = H(y_hat); d.ldh = ldh; d.H = Hh; d.W = W; d.C = C; d.nsteps = nsteps; d.step = step;
+        dcvc::mask_step_dec(d, S(stream));
+    });
+}
+
 int dcvc_gemm_timeline_buffer(void* device_buffer)
 {
     return dcvc::guarded([&] { dcvc::gemm_timeline_buffer(static_cast<long long*>(device_buffer)); });

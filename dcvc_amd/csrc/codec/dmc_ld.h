@@ -34,6 +34,13 @@ public:
 
     size_t debug_read(const std::string& name, void* dst, size_t cap, hipStream_t stream);
 
+    // Temporal state as one flat DEVICE buffer (reference feature, memory | feature_p, ctx, temporal
+    // prior + the validity flags in a 64-byte header): what another GPU needs to continue the same
+    // GOP (torch.distributed.send / recv over RCCL, dcvc_amd/sharding.py). export with dst == nullptr
+    // returns the size. import requires the same picture size and parameters.
+    size_t export_state(void* dst, size_t cap, hipStream_t stream);
+    void import_state(const void* src, size_t bytes, int height, int width, hipStream_t stream);
+
 private:
     struct Geometry {
         int H8 = 0, W8 = 0, H16 = 0, W16 = 0, H16p = 0, W16p = 0, H32 = 0, W32 = 0, H64 = 0, W64 = 0;

@@ -433,6 +433,79 @@ void DmcLdCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
     m_enc_ready = false;                   // the temporal params were consumed by this picture
 }
 
+// ------------------------------------------------------------------------------------ state hand-off
+namespace {
+
+struct StateHeader {
+    uint32_t magic, h8, w8, flags;
+    uint32_t reserved[12];
+};
+constexpr uint32_t kLdMagic = 0x44434c44;     // "DCLD"
+
+}  // namespace
+
+size_t DmcLdCodec::export_state(void* dst, size_t cap, hipStream_t user)
+{
+    if (!m_has_params || m_g.H8 == 0) throw std::runtime_error("DMC-LD export_state: no state yet");
+    const Geometry& g = m_g;
+    const size_t n_fi = static_cast<size_t>(g.P8()) * kChSrc, n_catm = static_cast<size_t>(g.P8()) * (kChM + kChD),
+                 n_ctx = static_cast<size_t>(g.P8()) * kChM, n_tp = static_cast<size_t>(g.P16()) * 2 * kChY;
+    const size_t bytes = sizeof(StateHeader) + 2 * (n_fi + n_catm + n_ctx + n_tp);
+    if (dst == nullptr) return bytes;
+    if (cap < bytes) throw std::invalid_argument("export_state: destination too small");
+    hipStream_t st = enter(user);
+    StateHeader h{};
+    h.magic = kLdMagic; h.h8 = g.H8; h.w8 = g.W8;
+    h.flags = (m_has_ref ? 1u : 0u) | (m_enc_ready ? 2u : 0u) | (m_memory_has_value ? 4u : 0u) | (m_has_feature_p ? 8u : 0u);
+    char* out = static_cast<char*>(dst);
+    hip_check(hipMemcpyAsync(out, &h, sizeof(h), hipMemcpyHostToDevice, st), "state header");
+    hip_check(hipStreamSynchronize(st), "sync");          // the header lives on this stack frame
+    out += sizeof(h);
+    auto put = [&](const half_t* p, size_t n) {
+        hip_check(hipMemcpyAsync(out, p, 2 * n, hipMemcpyDeviceToDevice, st), "state D2D");
+        out += 2 * n;
+    };
+    put(m_FI, n_fi);
+    put(m_CATM, n_catm);
+    // ctx and the temporal prior are channel slices of wider buffers: dense copies
+    hip_check(hipMemcpy2DAsync(out, 2 * kChM, m_CATD + kChD, 2 * (kChD + kChM), 2 * kChM, g.P8(), hipMemcpyDeviceToDevice, st), "state ctx");
+    out += 2 * n_ctx;
+    hip_check(hipMemcpy2DAsync(out, 4 * kChY, m_CATPF + kChY, 6 * kChY, 4 * kChY, g.P16(), hipMemcpyDeviceToDevice, st), "state temporal");
+    leave(user);
+    return bytes;
+}
+
+void DmcLdCodec::import_state(const void* src, size_t bytes, int height, int width, hipStream_t user)
+{
+    prepare(height, width);
+    const Geometry& g = m_g;
+    const size_t n_fi = static_cast<size_t>(g.P8()) * kChSrc, n_catm = static_cast<size_t>(g.P8()) * (kChM + kChD),
+                 n_ctx = static_cast<size_t>(g.P8()) * kChM, n_tp = static_cast<size_t>(g.P16()) * 2 * kChY;
+    if (bytes != sizeof(StateHeader) + 2 * (n_fi + n_catm + n_ctx + n_tp)) {
+        throw std::invalid_argument("import_state: size does not match this picture size");
+    }
+    hipStream_t st = enter(user);
+    StateHeader h{};
+    const char* in = static_cast<const char*>(src);
+    hip_check(hipMemcpyAsync(&h, in, sizeof(h), hipMemcpyDeviceToHost, st), "state header");
+    hip_check(hipStreamSynchronize(st), "sync");
+    if (h.magic != kLdMagic || h.h8 != static_cast<uint32_t>(g.H8) || h.w8 != static_cast<uint32_t>(g.W8)) {
+        throw std::invalid_argument("import_state: not a DMC-LD state of this picture size");
+    }
+    in += sizeof(h);
+    auto get = [&](half_t* p, size_t n) {
+        hip_check(hipMemcpyAsync(p, in, 2 * n, hipMemcpyDeviceToDevice, st), "state D2D");
+        in += 2 * n;
+    };
+    get(m_FI, n_fi);
+    get(m_CATM, n_catm);
+    hip_check(hipMemcpy2DAsync(m_CATD + kChD, 2 * (kChD + kChM), in, 2 * kChM, 2 * kChM, g.P8(), hipMemcpyDeviceToDevice, st), "state ctx");
+    in += 2 * n_ctx;
+    hip_check(hipMemcpy2DAsync(m_CATPF + kChY, 6 * kChY, in, 4 * kChY, 4 * kChY, g.P16(), hipMemcpyDeviceToDevice, st), "state temporal");
+    leave(user);
+    m_has_ref = h.flags & 1u; m_enc_ready = h.flags & 2u; m_memory_has_value = h.flags & 4u; m_has_feature_p = h.flags & 8u;
+}
+
 // ------------------------------------------------------------------------------------ debug
 size_t DmcLdCodec::debug_read(const std::string& name, void* dst, size_t cap, hipStream_t st)
 {

@@ -98,18 +98,27 @@ __device__ __forceinline__ const half_t* x_row_ptr(const ConvGemmParams& p, int 
     }
 }
 
-template <int WM, int WN, int MT, int NT, int STAGES, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
-__global__ void __launch_bounds__(WM * WN * 64)
+// XDIRECT: the activation operand does not pass through LDS. Each wave owns 32 pixel rows and ALL
+// channels of the tile (WN = 1), so no other wave needs its activation fragments: a lane loads
+// the 8 consecutive k values of its pixel straight from global memory into the MFMA operand
+// registers (16 B per lane and k-slice, one 128-B line per row and k-step). Only the weight tile
+// is staged in LDS - half the LDS fill traffic, all of it L2-resident weights - and the block
+// needs 64 KB instead of 128 KB of LDS, so two blocks share a CU and the epilogue of one overlaps
+// the main loop of the other.
+template <int WM, int WN, int MT, int NT, int STAGES, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE,
+          bool XDIRECT = false>
+__global__ void __launch_bounds__(WM * WN * 64, XDIRECT ? 2 : 1)
 conv_gemm_kernel(const ConvGemmParams p)
 {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
-    constexpr int XT_BYTES = BM * BK * 2;
+    constexpr int XT_BYTES = XDIRECT ? 0 : BM * BK * 2;
     constexpr int WT_BYTES = BN * BK * 2;
     constexpr int STAGE_BYTES = XT_BYTES + WT_BYTES;
-    constexpr int XU = BM * 8 / NTHREADS;      // 16-B units per thread and stage
+    constexpr int XU = XDIRECT ? 0 : BM * 8 / NTHREADS;      // 16-B units per thread and stage
     constexpr int WU = BN * 8 / NTHREADS;
+    static_assert(!XDIRECT || (WN == 1 && MT == 1 && STAGES == 2), "direct activation loads: one 32-row strip per wave");
     constexpr int ROWS_PER_PASS = NTHREADS / 8;
     static_assert(ROWS_PER_PASS % 16 == 0, "swizzle term must not depend on the pass");
     static_assert(!CHUNK || NT % 2 == 0, "chunk-add pairs two channel tiles");
@@ -152,7 +161,7 @@ conv_gemm_kernel(const ConvGemmParams p)
     //      unit u -> row u>>3, physical chunk u&7; logical chunk = physical ^ ((row>>1)&7)
     const int srow = tid >> 3;
     const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-    int xrow[XU];
+    int xrow[XU > 0 ? XU : 1];
     const half_t* wsrc[WU];
 #pragma unroll
     for (int j = 0; j < XU; ++j) xrow[j] = min(m0 + j * ROWS_PER_PASS + srow, p.M - 1);
@@ -190,8 +199,18 @@ conv_gemm_kernel(const ConvGemmParams p)
     const bool wave_active = (n0 + wn * (NT * 32)) < p.N;   // N is a multiple of NT*32 per wave
     const int nk = p.K / BK;
 
+    // direct activation fragments (XDIRECT): xnext = k-step t+1 in flight, xcur = k-step t in use
+    half8 xcur[4], xnext[4];
+    const int xdrow = min(m0 + wm * 32 + frow, p.M - 1);
+    auto load_x_direct = [&](int k0) {
+        const half_t* xp = x_row_ptr<SPATIAL>(p, xdrow, k0) + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xnext[s] = *reinterpret_cast<const half8*>(xp + 16 * s);
+    };
+
     // the first tile goes out before anything else touches the memory pipeline
     stage(0, 0, -1);
+    if constexpr (XDIRECT) load_x_direct(0);
     if constexpr (STAGES == 3) {
         if (nk > 1) stage(1, BK, -1);
     }
@@ -250,6 +269,11 @@ conv_gemm_kernel(const ConvGemmParams p)
             if (t < 8) stamp();                                    // 2..9: k-step t may start
             if (t == 0) load_residual();
             cur = t & 1;
+            if constexpr (XDIRECT) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xcur[s] = xnext[s];      // landed: the barrier drained vmcnt
+                if (t + 1 < nk) load_x_direct((t + 1) * BK);
+            }
         } else {
             // Two tiles in flight: wait only for the OLDER one (counted vmcnt), keep the younger
             // across the barrier. __syncthreads() would drain the LDS-DMA queue, hence the raw
@@ -272,16 +296,20 @@ conv_gemm_kernel(const ConvGemmParams p)
             // fragments of k-slice s+1 are fetched while the MFMAs of slice s run (register
             // double buffering; hipcc otherwise waits for all six reads in front of every slice)
             half8 xf[2][MT], wf[2][NT];
+            if constexpr (!XDIRECT) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) xf[0][i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[0]);
+                for (int i = 0; i < MT; ++i) xf[0][i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[0]);
+            }
 #pragma unroll
             for (int i = 0; i < NT; ++i) wf[0][i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[0]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (s < 3) {
+                    if constexpr (!XDIRECT) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        xf[(s + 1) & 1][i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s + 1]);
+                        for (int i = 0; i < MT; ++i)
+                            xf[(s + 1) & 1][i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s + 1]);
+                    }
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
                         wf[(s + 1) & 1][i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s + 1]);
@@ -289,8 +317,10 @@ conv_gemm_kernel(const ConvGemmParams p)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], xf[s & 1][mt], acc[nt][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const half8 xfrag = XDIRECT ? xcur[s] : xf[s & 1][mt];
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], xfrag, acc[nt][mt], 0, 0, 0);
+                    }
                 if constexpr (STAGES == 2) {
                     if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK, s);
                 }
@@ -477,14 +507,15 @@ GemmProfile& profile()
     return g;
 }
 
-template <int WM, int WN, int MT, int NT, int STAGES, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE>
+template <int WM, int WN, int MT, int NT, int STAGES, bool SPATIAL, int ACT, bool CHUNK, int NRES, bool QUANT, bool UPSAMPLE,
+          bool XDIRECT = false>
 void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
 {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHREADS = WM * WN * 64;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    auto kern = conv_gemm_kernel<WM, WN, MT, NT, STAGES, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>;
+    auto kern = conv_gemm_kernel<WM, WN, MT, NT, STAGES, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE, XDIRECT>;
     static bool attr_set = false;
-    const int smem_bytes = STAGES * (BM + BN) * BK * 2 + (ACT == ACT_WSILU ? WSILU_TABLE_BYTES : 0);
+    const int smem_bytes = STAGES * ((XDIRECT ? 0 : BM) + BN) * BK * 2 + (ACT == ACT_WSILU ? WSILU_TABLE_BYTES : 0);
     if (!attr_set) {
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
@@ -502,7 +533,7 @@ void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
         }
         pf.info[pf.used] = GemmLaunchInfo{ p.M, p.N, p.K,
                                            (SPATIAL ? 1 : 0) | (ACT << 1) | (CHUNK ? 4 : 0) | (NRES << 3) |
-                                               (QUANT ? 32 : 0) | (UPSAMPLE ? 64 : 0) | (BM << 8) | (BN << 18) | (STAGES << 28), 0.f };
+                                               (QUANT ? 32 : 0) | (UPSAMPLE ? 64 : 0) | (BM << 8) | (BN << 18) | (STAGES << 28) | (XDIRECT ? (1 << 30) : 0), 0.f };
         hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), smem_bytes, stream, pf.events[pf.used].first,
                               pf.events[pf.used].second, 0, p);
         ++pf.used;
@@ -536,6 +567,10 @@ void launch(ConvGemmParams p, hipStream_t stream)
         case 7: launch_cfg<4, 2, 2, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
         case 8: launch_cfg<2, 2, 2, 4, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
         case 9: launch_cfg<4, 1, 1, 4, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream); return;
+        case 10: launch_cfg<4, 1, 1, 8, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE, true>(p, stream); return;
+        case 11:
+            if constexpr (!CHUNK) { launch_cfg<4, 1, 1, 6, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE, true>(p, stream); return; }
+            break;
         default: break;
         }
     }

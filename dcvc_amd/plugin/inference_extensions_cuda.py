@@ -41,6 +41,8 @@ _LD = dict(
     decompress=_lib.fn("dcvc_dmcld_decompress", _ci,
                        [_vp, _vp, ctypes.c_size_t, _ci, _ci, _ci, _ci, _ci, _vp, _vp]),
     use_graphs=_lib.fn("dcvc_dmcld_set_use_graphs", _ci, [_vp, _ci]),
+    export_state=_lib.fn("dcvc_dmcld_export_state", ctypes.c_int64, [_vp, _vp, ctypes.c_size_t, _vp]),
+    import_state=_lib.fn("dcvc_dmcld_import_state", _ci, [_vp, _vp, ctypes.c_size_t, _ci, _ci, _vp]),
     debug_read=_lib.fn("dcvc_dmcld_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
 )
 
@@ -195,6 +197,26 @@ class DMCLDProxy(_Proxy):
                                      1 if reset_feature_memory else 0,
                                      ctypes.c_void_p(x_hat.data_ptr()), _stream_ptr()))
         return x_hat
+
+
+def _ld_export_state(self):
+    """-> uint8 CUDA tensor holding the temporal state (send it with torch.distributed.send)."""
+    n = _lib.check(_LD["export_state"](self._h, None, 0, _stream_ptr()))
+    buf = torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    _lib.check(_LD["export_state"](self._h, ctypes.c_void_p(buf.data_ptr()), n, _stream_ptr()))
+    return buf
+
+
+def _ld_import_state(self, state, height, width):
+    """state: uint8 CUDA tensor from export_state() of a codec with the same parameters."""
+    if state.dtype != torch.uint8 or not state.is_cuda or not state.is_contiguous():
+        raise ValueError("expected a contiguous uint8 CUDA tensor")
+    _lib.check(_LD["import_state"](self._h, ctypes.c_void_p(state.data_ptr()), state.numel(), int(height),
+                                   int(width), _stream_ptr()))
+
+
+DMCLDProxy.export_state = _ld_export_state
+DMCLDProxy.import_state = _ld_import_state
 
 
 class _DMCHTProxy(_Proxy):

@@ -89,3 +89,25 @@ def code_sharded(n_units, code_unit, dist=None):
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     local = [(i, code_unit(i)) for i in shard_range(n_units, rank, world)]
     return gather_units(local, dist)
+
+
+# ------------------------------------------------------------------ GOP hand-off between GPUs
+# Inside a GOP the coding order is strictly sequential, but WHERE the next picture is coded is free
+# as long as the temporal state travels with it: DMCLDProxy.export_state() packs it into one flat
+# uint8 device tensor (reference feature, memory, last decoded feature, context, temporal prior:
+# 84 MB at 1080p), which moves point-to-point over xGMI with backend "nccl" (= RCCL).
+def send_state(proxy, dst, dist):
+    state = proxy.export_state()
+    dev = state.device
+    dist.send(torch.tensor([state.numel()], dtype=torch.int64, device=dev), dst)
+    dist.send(state, dst)
+
+
+def recv_state(proxy, src, height, width, dist, device=None):
+    dev = device if device is not None else _device_for(dist)
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    dist.recv(n, src)
+    state = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    dist.recv(state, src)
+    proxy.import_state(state, height, width)
+    return state.numel()

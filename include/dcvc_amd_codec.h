@@ -92,6 +92,14 @@ int dcvc_dmcld_decompress(dcvc_dmcld* c, const uint8_t* bit_stream, size_t nbyte
                           int width, int ec_parallel, int reset_feature_memory, void* x_hat,
                           void* stream);
 
+/* Not part of the reference surface - hand-off of a GOP to another GPU (north_star: temporal
+ * context exchanged point-to-point over xGMI): the temporal state (reference feature, memory,
+ * last decoded feature, context, temporal prior, validity flags) as ONE flat device buffer that
+ * torch.distributed.send / recv (RCCL) can move. export with dst == NULL returns the size in bytes;
+ * import needs a codec with the same parameters and picture size. */
+int64_t dcvc_dmcld_export_state(dcvc_dmcld* c, void* dst, size_t cap, void* stream);
+int dcvc_dmcld_import_state(dcvc_dmcld* c, const void* src, size_t bytes, int height, int width, void* stream);
+
 int dcvc_dmcld_set_use_graphs(dcvc_dmcld* c, int on);
 /* Test hook ("y", "y_hat", "common", "means1", "z_i8", "memory", "feature_p", "ctx", "temporal",
  * "feature_i", "symbols", "totals"); dense copy, returns the size in bytes. */

@@ -99,6 +99,26 @@ int dcvc_y_step_dec_restore(const void* decoded, const void* cond, const void* b
                             const void* totals, const void* means, int ldm,
                             void* y_hat_acc, int ldacc, int H, int W, int C, int step, void* stream);
 
+/* The inter models' full-tensor masked steps (nsteps = 2: LD checkerboard x channel halves,
+ * dmc_ld_proxy.cpp:672-683; nsteps = 4: HT-S channel-group x 2x2-position masks,
+ * dmc_hts_proxy.cpp:869-890). One call = one step of
+ *   divide_with_clamp_min_inplace_cuda (step 0) + process_with_mask_no_scale[_add[_and_multiply]]_inplace_cuda
+ *   (+ build_index_enc_cuda + conditional_index_part1_cuda on the last step, compacted symbols -> compact_out,
+ *   count -> totals[0]).
+ * y is rescaled in place at step 0; y_hat accumulates over the steps and is final after the last. */
+int dcvc_mask_step_enc(void* y, int ldy, const void* q_dec, int ldq, const void* scales, int lds,
+                       const void* means, int ldm, void* y_hat, int ldh, void* sym, void* cond,
+                       void* block_count, void* compact_out, void* totals, int H, int W, int C,
+                       int nsteps, int step, float skip_thres, void* stream);
+/* build_index_dec_cuda + conditional_index_part1_cuda over all channels */
+int dcvc_mask_dec_index(const void* scales, int lds, void* index, void* cond, void* block_count,
+                        void* compact_out, void* totals, int H, int W, int C, float skip_thres, void* stream);
+/* conditional_recover_with_type_conversion_cuda (step 0) + restore_y[_and_add[_multiply]]_inplace_cuda;
+ * yq: int8 scratch [H*W*C] carried from step 0 to the later steps */
+int dcvc_mask_step_dec(const void* decoded, const void* cond, const void* block_count, const void* totals,
+                       void* yq, const void* means, int ldm, const void* q_dec, int ldq, void* y_hat, int ldh,
+                       int H, int W, int C, int nsteps, int step, void* stream);
+
 /* Measurement hook (bench.py roofline leg, not a reference entry point): bracket every
  * contraction launch with HIP events on its stream; collect = summed kernel milliseconds,
  * algorithmic FLOPs (2*M*N*K) and launch count since the last reset. Graph replay must be off. */

@@ -34,6 +34,12 @@ class Ops:
                                                              ci, ci, ci, ci, cf, vp])
         self.y_step_dec_restore = _f("dcvc_y_step_dec_restore", [vp, vp, vp, vp, vp, ci, vp, ci,
                                                                  ci, ci, ci, ci, vp])
+        self.mask_step_enc = _f("dcvc_mask_step_enc", [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp,
+                                                       ci, ci, ci, ci, ci, cf, vp])
+        self.mask_dec_index = _f("dcvc_mask_dec_index", [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, cf, vp])
+        self.mask_step_dec = _f("dcvc_mask_step_dec", [vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci,
+                                                       ci, ci, ci, ci, ci, vp])
+        self.scale_clamped = _f("dcvc_scale_clamped", [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp])
 
 
 def ptr(t):

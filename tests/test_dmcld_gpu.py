@@ -167,3 +167,39 @@ def test_corrupt_stream_does_not_crash():
     d = dec.decompress(bytes(bad[:len(bad) // 2]), {"height": 64, "width": 64}, 20, r["ec_parallel"], 0)
     torch.cuda.synchronize()
     assert torch.isfinite(d["x_hat"].float()).all()
+
+
+def test_gop_hand_off_continues_bit_exactly():
+    """north_star (e): a GOP may move to another GPU between two pictures. Encoder and decoder
+    state exported after picture 2 and imported into fresh codec objects continue with exactly the
+    bytes / pixels of the uninterrupted codecs (same GPU here; the buffer is what
+    dcvc_amd.sharding.send_state / recv_state move over RCCL)."""
+    m = dmc_ld_model(skip_thres=0.15)
+    hw = (96, 160)
+    ref = to_device_input(_padded(picture(*hw, index=0)))
+    xs = [to_device_input(picture(*hw, index=i + 1)) for i in range(4)]
+    sps = {"height": hw[0], "width": hw[1]}
+    enc, dec, enc2, dec2 = _gpu_net(m), _gpu_net(m), _gpu_net(m), _gpu_net(m)
+    pb, pr = _pads(enc, *hw)
+    enc.add_ref_feature_from_frame(ref)
+    dec.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+    plan = [(30, 0), (34, 1), (30, 0), (34, 0)]
+    want = []
+    for i, ((qp, reset), x) in enumerate(zip(plan, xs)):
+        if i == 2:      # hand the GOP over before picture 2
+            s_enc, s_dec = enc.proxy.export_state(), dec.proxy.export_state()
+            assert s_enc.dtype == torch.uint8 and s_enc.numel() == s_dec.numel() > 1000
+            enc2._ensure_proxy().import_state(s_enc, hw[0], hw[1])
+            dec2._ensure_proxy().import_state(s_dec, hw[0], hw[1])
+        r = enc.compress(x, qp, reset, pb, pr)
+        d = dec.decompress(r["bit_stream"], sps, qp, r["ec_parallel"], reset)["x_hat"].clone()
+        want.append((r["bit_stream"], d))
+    for i in (2, 3):
+        qp, reset = plan[i]
+        r = enc2.compress(xs[i], qp, reset, pb, pr)
+        d = dec2.decompress(r["bit_stream"], sps, qp, r["ec_parallel"], reset)["x_hat"]
+        torch.cuda.synchronize()
+        assert r["bit_stream"] == want[i][0], "picture %d after the hand-off" % i
+        assert torch.equal(d, want[i][1])
+    with pytest.raises(Exception, match="picture size"):
+        enc2.proxy.import_state(s_enc, 64, 64)

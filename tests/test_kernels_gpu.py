@@ -3,6 +3,8 @@
 Dense convolutions are checked against a plain PyTorch fp32 reference of the same op (fp16
 inputs, fp32 math, one rounding) within a 1-2 fp16-ulp tolerance; integer / layout / symbol
 kernels are checked bit-exactly against the numpy oracle (oracle/symbols_np.py)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -284,3 +286,84 @@ def test_y_steps_exact(ops, H, W, thres):
         torch.cuda.synchronize()
         base += k
     assert np.array_equal(acc_d.cpu().numpy(), want_acc), "decoder y_hat_so_far == encoder's"
+
+
+@pytest.mark.parametrize("nsteps,H,W,C,thres", [(2, 17, 30, 128, 0.15), (4, 8, 8, 256, 0.0), (2, 68, 120, 128, 0.15),
+                                                (4, 68, 120, 256, 0.15), (4, 5, 3, 256, 0.15)])
+def test_mask_steps_exact(ops, nsteps, H, W, C, thres):
+    """The inter models' full-tensor masked steps (LD: 2, HT-S: 4): divide, quantise step by step
+    against changing means, final multiply, ONE index/compaction over all channels; then the
+    decoder side from the "decoded" symbols - bit-exact against oracle/symbols_np.py, operands as
+    channel slices of a wider buffer (the codecs' concatenation views)."""
+    from gpu_util import call, ptr, stream
+    from oracle import symbols_np as orc
+    dev = "cuda"
+    y = _rand((H, W, C), 6.0, 71)
+    common = torch.zeros((H, W, 3 * C), dtype=torch.half)
+    common[..., :C] = (_rand((H, W, C), 0.6, 72) + 0.9).half()              # q_dec, some below 0.5
+    common[0, 0, :4] = torch.tensor([0.25, 0.5, -1.0, 3.0]).half()
+    common[..., C:2 * C] = (_rand((H, W, C), 1.0, 73).float().exp() * 0.3).half()   # scales
+    common[..., 2 * C:] = _rand((H, W, C), 2.0, 74)                          # means of step 0
+    later_means = [_rand((H, W, C), 2.0, 75 + i) for i in range(nsteps - 1)]
+    q_np, sc_np = common[..., :C].numpy(), common[..., C:2 * C].numpy()
+    masks = orc.get_mask_2x(H, W, C) if nsteps == 2 else orc.get_mask_4x(H, W, C)
+    # oracle
+    y_div = orc.divide_with_clamp(y.numpy(), q_np)
+    y_q_all = np.zeros((H, W, C), np.float16)
+    y_hat = np.zeros((H, W, C), np.float16)
+    for k in range(nsteps):
+        mk = common[..., 2 * C:].numpy() if k == 0 else later_means[k - 1].numpy()
+        yq, yh = orc.process_with_mask_2x(y_div, sc_np, mk, masks[k], thres)
+        y_q_all = (y_q_all + yq).astype(np.float16)
+        y_hat = (y_hat + yh).astype(np.float16)
+    y_hat = (y_hat * orc.clamp_min_half(q_np)).astype(np.float16)
+    comb, keep = orc.build_index_enc(y_q_all, sc_np, thres)
+    # device, encoder side
+    n = H * W * C
+    yd, cd = y.to(dev), common.to(dev)
+    cat = torch.full((H, W, 2 * C), 5.0, dtype=torch.half, device=dev)     # y_hat lives in channels 0..C-1
+    sym = torch.zeros(n, dtype=torch.int16, device=dev)
+    cond = torch.zeros((n + 7) // 8 + 8, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(ops.symbol_blocks(n), dtype=torch.int32, device=dev)
+    comp = torch.zeros(n, dtype=torch.int16, device=dev)
+    totals = torch.zeros(4, dtype=torch.int32, device=dev)
+    eb = 2      # bytes per fp16
+    for k in range(nsteps):
+        if k == 0:
+            mp, ldm = cd.data_ptr() + 2 * C * eb, 3 * C
+        else:
+            md = later_means[k - 1].to(dev)
+            mp, ldm = md.data_ptr(), C
+        call(ops.mask_step_enc, ptr(yd), C, ptr(cd), 3 * C, ctypes.c_void_p(cd.data_ptr() + C * eb), 3 * C,
+             ctypes.c_void_p(mp), ldm, ptr(cat), 2 * C, ptr(sym), ptr(cond), ptr(cnt), ptr(comp), ptr(totals),
+             H, W, C, nsteps, k, thres, stream())
+        torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y_div), "y / max(q, 0.5)"
+    assert np.array_equal(sym.cpu().numpy(), comb)
+    assert np.array_equal(cat[..., :C].cpu().numpy(), y_hat)
+    assert (cat[..., C:] == 5.0).all(), "neighbouring channels untouched"
+    k_enc = int(totals.cpu()[0])
+    assert k_enc == int(keep.sum()) and np.array_equal(comp.cpu().numpy()[:k_enc], comb[keep])
+    # decoder side
+    idx = torch.zeros(n, dtype=torch.uint8, device=dev)
+    cidx = torch.zeros(n, dtype=torch.uint8, device=dev)
+    totals_d = torch.zeros(4, dtype=torch.int32, device=dev)
+    call(ops.mask_dec_index, ctypes.c_void_p(cd.data_ptr() + C * eb), 3 * C, ptr(idx), ptr(cond), ptr(cnt),
+         ptr(cidx), ptr(totals_d), H, W, C, thres, stream())
+    torch.cuda.synchronize()
+    widx, wkeep = orc.build_index_dec(sc_np, thres)
+    assert np.array_equal(idx.cpu().numpy(), widx) and int(totals_d.cpu()[0]) == k_enc
+    assert np.array_equal(cidx.cpu().numpy()[:k_enc], widx[wkeep])
+    decoded = torch.from_numpy((comb[keep] >> 8).astype(np.int8)).to(dev) if k_enc else torch.zeros(1, dtype=torch.int8, device=dev)
+    yqs = torch.zeros(n, dtype=torch.int8, device=dev)
+    cat_d = torch.full((H, W, 2 * C), -3.0, dtype=torch.half, device=dev)
+    for k in range(nsteps):
+        if k == 0:
+            mp, ldm = cd.data_ptr() + 2 * C * eb, 3 * C
+        else:
+            md = later_means[k - 1].to(dev)
+            mp, ldm = md.data_ptr(), C
+        call(ops.mask_step_dec, ptr(decoded), ptr(cond), ptr(cnt), ptr(totals_d), ptr(yqs), ctypes.c_void_p(mp), ldm,
+             ptr(cd), 3 * C, ptr(cat_d), 2 * C, H, W, C, nsteps, k, stream())
+        torch.cuda.synchronize()
+    assert np.array_equal(cat_d[..., :C].cpu().numpy(), y_hat), "decoder y_hat == encoder's"

@@ -66,3 +66,46 @@ def test_two_ranks_collect_units_in_order(tmp_path, n_units):
 
 def test_single_process_path():
     assert sharding.code_sharded(5, _fake_code) == [_fake_code(i) for i in range(5)]
+
+
+class _FakeProxy:
+    """Stands in for DMCLDProxy on the CPU: the hand-off helpers only move its opaque state."""
+
+    def __init__(self, fill=None):
+        self.state = None if fill is None else torch.arange(fill, dtype=torch.int64).to(torch.uint8)
+        self.size = None
+
+    def export_state(self):
+        return self.state
+
+    def import_state(self, state, height, width):
+        self.state, self.size = state.clone(), (height, width)
+
+
+def _handoff_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if rank == 0:
+            sharding.send_state(_FakeProxy(fill=100001), 1, dist)
+        else:
+            p = _FakeProxy()
+            n = sharding.recv_state(p, 0, 1080, 1920, dist)
+            with open(out_path, "wb") as f:
+                pickle.dump((n, p.size, p.state.numpy().tobytes()), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gop_state_hand_off_between_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "state.pkl")
+    mp.spawn(_handoff_worker, args=(2, port, out), nprocs=2, join=True)
+    with open(out, "rb") as f:
+        n, size, data = pickle.load(f)
+    want = torch.arange(100001, dtype=torch.int64).to(torch.uint8).numpy().tobytes()
+    assert n == 100001 and size == (1080, 1920) and data == want
