@@ -1,6 +1,6 @@
-"""smoke(): one small invocation of the hot path on cuda:0, checked against the oracle:
-DMCI compress + decompress of a 64x64 picture through the reference's plugin surface; the rANS
-bytes and the reconstruction must equal the CPU oracle's bit for bit."""
+"""smoke(): one small invocation of the hot path on cuda:0, checked against the oracle: an I picture
+(DMCI) followed by a P picture (DMC low-delay) of a 64x64 sequence through the reference's plugin
+surface; rANS bytes and reconstructions must equal the CPU oracle's bit for bit."""
 import copy
 import os
 import sys
@@ -28,3 +28,21 @@ def run():
     assert torch.equal(dec["x_hat"], got["x_hat"])
     print("smoke ok: DMCI 64x64 qp32 -> %d bytes, bit-exact vs oracle, decode closure ok"
           % len(got["bit_stream"]))
+    # P picture on the intra reconstruction (test_video.py:226-238)
+    from codec_util import dmc_ld_model
+    mp = dmc_ld_model(skip_thres=0.15)
+    enc, dec_p = copy.deepcopy(mp).half().cuda(), copy.deepcopy(mp).half().cuda()
+    enc.proxy = dec_p.proxy = None
+    enc.add_ref_feature_from_frame(got["x_hat"])
+    dec_p.add_ref_feature_from_frame(dec["x_hat"], apply_feature_adaptor=False)
+    eo, do = oracle_for(mp), oracle_for(mp)
+    eo.add_ref_feature_from_frame(want["x_hat"], True)
+    do.add_ref_feature_from_frame(want["x_hat"], False)
+    x1 = picture(64, 64, index=1)
+    gp = enc.compress(to_device_input(x1), 30, 0, 0, 0)
+    wp = eo.compress(x1, 30, False)
+    assert gp["bit_stream"] == wp["bit_stream"], "P-picture bit stream differs from the oracle"
+    xd = dec_p.decompress(gp["bit_stream"], {"height": 64, "width": 64}, 30, gp["ec_parallel"], 0)["x_hat"]
+    torch.cuda.synchronize()
+    assert np.array_equal(from_device_output(xd), do.decompress(wp["bit_stream"], 30, 64, 64, wp["ec_parallel"], False))
+    print("smoke ok: DMC-LD P picture qp30 -> %d bytes, bit-exact vs oracle" % len(gp["bit_stream"]))
