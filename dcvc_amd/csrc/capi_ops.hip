@@ -106,6 +106,20 @@ int dcvc_mul_channel(const void* x, int ldx, const void* q, void* y, int ldy, in
     return dcvc::guarded([&] { dcvc::mul_channel(H(x), ldx, H(q), H(y), ldy, pixels, C, S(stream)); });
 }
 
+int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const void* w2, const void* b2,
+                   const void* r2, int ldr2, const void* q, const void* q2, void* y, int ldy,
+                   int pixels, int c, int cffn, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::kernels_init();
+        dcvc::FfnFusedDesc d;
+        d.x = H(x); d.ldx = ldx; d.w0 = H(w0); d.b0 = H(b0); d.w2 = H(w2); d.b2 = H(b2);
+        d.r2 = H(r2); d.ldr2 = ldr2; d.q = H(q); d.q2 = H(q2); d.y = H(y); d.ldy = ldy;
+        d.pixels = pixels; d.c = c; d.cffn = cffn;
+        dcvc::ffn_fused(d, S(stream));
+    });
+}
+
 int dcvc_scale_clamped(const void* x, int ldx, const void* q, int ldq, void* y, int ldy, int pixels,
                        int C, int reciprocal, void* stream)
 {

@@ -192,6 +192,16 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         d.y = y.p; d.ldy = y.ld; d.pixels = P; d.cin = cdc; d.cout = c;
         conv1x1(d, st);
     }
+    if (ffn_fused_supported(P, c, cffn) && ffn0.b != nullptr && ffn2.b != nullptr) {
+        // ffn.0 + ffn.2 in one launch: the chunk-added tensor stays in LDS (kernels/ffn_fused.hip)
+        FfnFusedDesc d;
+        d.x = y.p; d.ldx = y.ld; d.w0 = ffn0.w; d.b0 = ffn0.b; d.w2 = ffn2.w; d.b2 = ffn2.b;
+        if (shortcut) { d.r2 = in.p; d.ldr2 = in.ld; }
+        d.q = q_fused; d.q2 = q_after;
+        d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.cffn = cffn;
+        ffn_fused(d, st);
+        return;
+    }
     {   // ffn.0 + WSiLU + chunk-add: the 4x expanded tensor never reaches HBM
         Conv1x1Desc d;
         d.x = y.p; d.ldx = y.ld; d.w = ffn0.w; d.bias = ffn0.b; d.wsilu = true; d.chunk_add = true;

@@ -480,7 +480,9 @@ conv_gemm_kernel(const ConvGemmParams p)
 
 long long* g_timeline = nullptr;       // tools/gemm_timeline.py: device buffer for the in-kernel stamps
 
-// ---- WSiLU table in device memory (uploaded once, outside any capture)
+}  // namespace
+
+// ---- WSiLU table in device memory (uploaded once, outside any capture); shared with ffn_fused.hip
 const float4* wsilu_table_device()
 {
     static float4* dev = nullptr;
@@ -491,6 +493,8 @@ const float4* wsilu_table_device()
     });
     return dev;
 }
+
+namespace {
 
 // ---- optional per-launch timing (bench.py's roofline leg): hipExtLaunchKernel stamps the
 // kernel's own begin / end into the two events

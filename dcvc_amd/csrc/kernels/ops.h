@@ -74,6 +74,27 @@ struct TConv2x2Desc {
 };
 void tconv2x2(const TConv2x2Desc& d, hipStream_t stream);
 
+// ---------------------------------------------------------------- fused FFN (ffn_fused.hip)
+// out = W2 * chunk_add(WSiLU(W0 * x + b0)) + b2 + x [+ r2] [* q]  (then [* q2] on the rounded
+// output): ffn.0 and ffn.2 of a DepthConvBlock (layers_proxy.cpp:84-98) in one launch, bit-identical
+// to conv1x1(wsilu, chunk_add) followed by conv1x1(r1 = x, ...). y may alias x.
+struct FfnFusedDesc {
+    const half_t* x = nullptr; int ldx = 0;     // [pixels][ldx], first c channels
+    const half_t* w0 = nullptr;                 // [4*cffn][c]
+    const half_t* b0 = nullptr;                 // [4*cffn]
+    const half_t* w2 = nullptr;                 // [c][cffn]
+    const half_t* b2 = nullptr;                 // [c]
+    const half_t* r2 = nullptr; int ldr2 = 0;   // optional second residual
+    const half_t* q = nullptr;                  // optional fused scale
+    const half_t* q2 = nullptr;                 // optional scale on the rounded output
+    half_t* y = nullptr; int ldy = 0;
+    int pixels = 0, c = 0, cffn = 0;
+};
+// shapes the fused kernel takes (c in {128, 256, 384}, cffn % 64 == 0) AND that are large enough to
+// fill the chip with 128-row strips; DCVC_FFN_FUSED=0 switches the fusion off (A/B measurements)
+bool ffn_fused_supported(int pixels, int c, int cffn);
+void ffn_fused(const FfnFusedDesc& d, hipStream_t stream);
+
 // ---------------------------------------------------------------- depthwise 3x3 (dwconv.hip)
 // y[h][w][c] = sum_{ky,kx} x[h+ky-1][w+kx-1][c] * wt[ky][kx][c]   (zero padding, no bias: the
 // reference folds the bias into the next 1x1, layers_proxy.cpp:175-178)

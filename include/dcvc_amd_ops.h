@@ -55,6 +55,14 @@ int dcvc_crop(const void* in, int ldin, int Win, void* out, int ldout, int H, in
 int dcvc_mul_channel(const void* x, int ldx, const void* q, void* y, int ldy, int pixels, int C,
                      void* stream);
 
+/* ffn.0 + ffn.2 of a DepthConvBlock in one launch (layers_proxy.cpp:84-98: conv1x1_bias_wsilu_chunk_add
+ * followed by conv1x1_bias_shortcut[2][_with_quant] with the block-internal tensor as first residual):
+ *   out = W2 * chunk_add(WSiLU(W0 * x + b0)) + b2 + x [+ r2] [* q], rounded to fp16, [* q2].
+ * c in {128, 256, 384}, cffn a multiple of 64; bit-identical to the two-launch sequence; y may alias x. */
+int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const void* w2, const void* b2,
+                   const void* r2, int ldr2, const void* q, const void* q2, void* y, int ldy,
+                   int pixels, int c, int cffn, void* stream);
+
 /* stream.cu:40-76 / 422-443: y = x * max(q, 0.5) or, with reciprocal != 0, y = x * fp16(1 / max(q, 0.5));
  * q is a tensor of the same shape (the inter models' per-element quantisation step). */
 int dcvc_scale_clamped(const void* x, int ldx, const void* q, int ldq, void* y, int ldy, int pixels,

@@ -39,6 +39,7 @@ class Ops:
         self.mask_dec_index = _f("dcvc_mask_dec_index", [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, cf, vp])
         self.mask_step_dec = _f("dcvc_mask_step_dec", [vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci,
                                                        ci, ci, ci, ci, ci, vp])
+        self.ffn_fused = _f("dcvc_ffn_fused", [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp])
         self.scale_clamped = _f("dcvc_scale_clamped", [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp])
 
 

@@ -367,3 +367,50 @@ def test_mask_steps_exact(ops, nsteps, H, W, C, thres):
              ptr(cd), 3 * C, ptr(cat_d), 2 * C, H, W, C, nsteps, k, stream())
         torch.cuda.synchronize()
     assert np.array_equal(cat_d[..., :C].cpu().numpy(), y_hat), "decoder y_hat == encoder's"
+
+
+@pytest.mark.parametrize("P,C,CF,res2,quant,q2,inplace", [
+    (300, 384, 384, False, False, False, True),
+    (1024, 256, 128, True, False, False, True),
+    (130, 128, 64, False, True, True, False),
+    (2040, 384, 384, True, False, True, False),
+    (32640, 384, 384, False, False, True, True),
+    (32640, 256, 128, False, True, False, True),
+])
+def test_ffn_fused_equals_two_launches(ops, P, C, CF, res2, quant, q2, inplace):
+    """ffn.0 + ffn.2 in one launch == conv1x1(wsilu, chunk_add) followed by conv1x1(residuals, quant),
+    bit for bit (the two-launch kernels are themselves checked against the oracle above)."""
+    from gpu_util import call, ptr, stream
+    dev = "cuda"
+    ld = C + 64                                            # a channel slice of a wider buffer
+    xbuf = _rand((P, ld), 1.0, 91).to(dev)
+    w0 = (_rand((4 * CF, C), 1.0, 92) / C ** 0.5).half().to(dev)
+    b0 = _rand((4 * CF,), 0.3, 93).to(dev)
+    w2 = (_rand((C, CF), 1.0, 94) / CF ** 0.5).half().to(dev)
+    b2 = _rand((C,), 0.3, 95).to(dev)
+    r2 = _rand((P, C), 1.0, 96).to(dev) if res2 else None
+    q = (_rand((C,), 0.2, 97) + 1.0).half().to(dev) if quant else None
+    qq = (_rand((C,), 0.2, 98) + 1.0).half().to(dev) if q2 else None
+    # two launches
+    t = torch.zeros((P, CF), dtype=torch.half, device=dev)
+    want = torch.zeros((P, C), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(xbuf), ld, ptr(w0), ptr(b0), None, 0, None, 0, None, None, ptr(t), CF, P, C, 4 * CF, 3, stream())
+    call(ops.conv1x1, ptr(t), CF, ptr(w2), ptr(b2), ptr(xbuf), ld, ptr(r2), C, ptr(q), ptr(qq), ptr(want), C, P, CF, C, 0, stream())
+    torch.cuda.synchronize()
+    # one launch
+    if inplace:
+        ybuf, ldy = xbuf.clone(), ld
+        xin = ybuf
+    else:
+        ybuf, ldy = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev), C + 8
+        xin = xbuf
+    call(ops.ffn_fused, ptr(xin), ld, ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(r2), C, ptr(q), ptr(qq), ptr(ybuf), ldy,
+         P, C, CF, stream())
+    torch.cuda.synchronize()
+    got = ybuf[:, :C]
+    bad = int((got != want).sum())
+    assert bad == 0, "%d of %d outputs differ" % (bad, want.numel())
+    if inplace:
+        assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
+    else:
+        assert (ybuf[:, C:] == 9.0).all()
