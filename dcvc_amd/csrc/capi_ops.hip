@@ -120,6 +120,20 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
     });
 }
 
+int dcvc_dcb_tail(const void* t, int ldt, const void* dw, const void* x, int ldx, const void* w3, const void* b3,
+                  const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                  void* y, int ldy, int Hh, int W, int c, int cdc, int cffn, int shortcut, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::kernels_init();
+        dcvc::DcbTailDesc d;
+        d.t = H(t); d.ldt = ldt; d.dw = H(dw); d.x = H(x); d.ldx = ldx; d.w3 = H(w3); d.b3 = H(b3);
+        d.w0 = H(w0); d.b0 = H(b0); d.w2 = H(w2); d.b2 = H(b2); d.q = H(q); d.q2 = H(q2);
+        d.y = H(y); d.ldy = ldy; d.H = Hh; d.W = W; d.c = c; d.cdc = cdc; d.cffn = cffn; d.shortcut = shortcut != 0;
+        dcvc::dcb_tail(d, S(stream));
+    });
+}
+
 int dcvc_scale_clamped(const void* x, int ldx, const void* q, int ldq, void* y, int ldy, int pixels,
                        int C, int reciprocal, void* stream)
 {

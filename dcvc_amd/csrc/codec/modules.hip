@@ -185,6 +185,16 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         d.y = s.t1; d.ldy = cdc; d.pixels = P; d.cin = c; d.cout = cdc;
         conv1x1(d, st);
     }
+    if (dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr && dc3.b != nullptr) {
+        // depthwise + dc.3 + ffn.0 + ffn.2 in one launch (kernels/dcb_tail.hip)
+        DcbTailDesc d;
+        d.t = s.t1; d.ldt = cdc; d.dw = dw; d.x = in.p; d.ldx = in.ld;
+        d.w3 = dc3.w; d.b3 = dc3.b; d.w0 = ffn0.w; d.b0 = ffn0.b; d.w2 = ffn2.w; d.b2 = ffn2.b;
+        d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld;
+        d.H = H; d.W = W; d.c = c; d.cdc = cdc; d.cffn = cffn; d.shortcut = shortcut;
+        dcb_tail(d, st);
+        return;
+    }
     dwconv3x3(s.t1, cdc, dw, s.t2, cdc, H, W, cdc, st);
     {   // dc.3 (+ folded depthwise bias) + shortcut
         Conv1x1Desc d;

@@ -1,0 +1,489 @@
+// dcb_tail.hip - everything of a half-width DepthConvBlock behind its first 1x1 conv in ONE launch:
+//
+//     t2  = depthwise3x3(t1)                                  dc.2  (d3x3, bias folded into dc.3)
+//     y1  = W3 * t2 + b3' + x                                  dc.3  (conv1x1_bias_shortcut)
+//     t   = chunk_add(WSiLU(W0 * y1 + b0))                     ffn.0 (conv1x1_bias_wsilu_chunk_add)
+//     out = W2 * t + b2 + y1 [+ x] [* q]                       ffn.2 (conv1x1_bias_shortcut[2][_with_quant])
+//
+// Reference: layers_proxy.cpp:79-98 = four launches with t2, y1 and t round-tripping through memory.
+// The inter models' blocks are narrow (C = 256 or 128, inner widths C/2), their per-launch work is
+// a few microseconds and the launch boundaries (kernel drain + L2 write-back of the dirty output,
+// ~3-4 us each on the 8-XCD part) cost as much as the kernels. Here a workgroup owns an 8 x 16
+// patch of pixels (128 rows) and keeps everything behind the depthwise on chip:
+//
+//   phase 0  t2 rows of the patch from t1 and its 1-pixel halo (global loads, L2-resident: dc.0
+//            wrote t1 just before), fp32 fmaf chain in tap order, -> fp16 -> LDS operand slabs
+//   phase 1  y1 = dc.3: all of W3 is staged at once (C x C/2 fits), K = C/2 -> accumulators
+//            + residual x -> fp16 -> LDS operand slabs, resident until the end
+//   phase 2  the fused FFN of ffn_fused.hip with its activation operand read from the resident y1
+//   final    out = acc2 + y1 (from LDS) [+ x] [* q] -> whole-line stores
+//
+// Every fp16 rounding point and every contraction order is that of the four-launch path, so the
+// result is bit-identical to it (tests/test_kernels_gpu.py::test_dcb_tail_equals_four_launches).
+#include "arith.h"
+#include "ops.h"
+#include "wsilu_table.h"
+
+#include <cstdlib>
+
+namespace dcvc {
+
+const float4* wsilu_table_device();      // conv_gemm.hip
+
+namespace {
+
+constexpr int NTHREADS = 512;
+constexpr int BM = 128;                  // pixel rows per workgroup: an 8 x 16 patch
+constexpr int PH = 8, PW = 16;
+constexpr int BNA = 256;                 // ffn.0 output channels per tile (64 channels of t)
+constexpr int WT_BYTES = BNA * 128;      // W0 slab [256][64]: 32 KB
+constexpr int SLAB_BYTES = BM * 128;     // activation slab [128 rows][64 k]: 16 KB
+constexpr int ST_BYTES = 2 * WT_BYTES;   // stage area: 64 KB
+constexpr int TABLE_BYTES = WSILU_SEGMENTS * 16;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct TailParams {
+    const half_t* t1;     // dc.0 output [H*W][ldt], first CD channels (DW) / dc.2 output (no DW)
+    const half_t* dw;     // depthwise weights [9][CD] (DW only)
+    const half_t* x;      // block-internal input [H*W][ldx]: residual of dc.3 (and of ffn.2 when `r2x`)
+    const half_t* w3;     // [C][CD]
+    const half_t* b3;     // [C] (depthwise bias folded in)
+    const half_t* w0;     // [4*CF][C]
+    const half_t* b0;
+    const half_t* w2;     // [C][CF]
+    const half_t* b2;
+    const half_t* q;
+    const half_t* q2;
+    const float4* wsilu;
+    half_t* y;            // [H*W][ldy]; may alias x
+    int ldt, ldx, ldy;
+    int H, W, CD, CF;
+    int r2x;              // ffn.2's second residual = x (block-level shortcut)
+};
+
+template <int NT2, bool DW, bool QUANT>
+__global__ void __launch_bounds__(NTHREADS)
+dcb_tail_kernel(const TailParams p)
+{
+    constexpr int C = NT2 * 128;
+    constexpr int NKC = C / 64;                      // operand slabs of y1
+    constexpr int Y1_BYTES = NKC * SLAB_BYTES;       // 64 KB (C = 256) / 32 KB (C = 128)
+    constexpr int ST_OFF = Y1_BYTES;
+    constexpr int TAB_OFF = ST_OFF + ST_BYTES;
+    constexpr int WU = BNA * 8 / NTHREADS;           // 4
+    constexpr int W2U = C * 8 / NTHREADS;            // W2 slab [C][64]
+    constexpr int W3U = C * 8 / NTHREADS;            // W3 slab [C][64]
+    constexpr int SLAB2_OFF = ST_OFF + SLAB_BYTES;   // behind T
+    constexpr int REP_OFF = SLAB2_OFF + C * 128;
+    constexpr int REP_FREE = ST_OFF + ST_BYTES - REP_OFF;
+    constexpr int R = REP_FREE >= 16 * TABLE_BYTES ? 16 : REP_FREE >= 8 * TABLE_BYTES ? 8
+                    : REP_FREE >= 4 * TABLE_BYTES ? 4 : REP_FREE >= 2 * TABLE_BYTES ? 2 : 1;
+    constexpr int OCH = C / 8;
+    constexpr int OUNITS = BM * OCH / NTHREADS;
+    static_assert(BM * C * 2 <= ST_BYTES && REP_OFF <= ST_OFF + ST_BYTES, "output tile / W2 slab must fit the stage area");
+    static_assert(C * 128 <= Y1_BYTES, "a W3 slab must fit the y1 area per operand slab");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int hi = lane >> 5;
+    const int frow = lane & 31;
+    const int npx = (p.W + PW - 1) / PW;
+    const int py = blockIdx.x / npx, px = blockIdx.x - py * npx;
+    const int nkd = p.CD >> 6;                       // operand slabs of t2 (1 or 2 ... up to NKC)
+    const int nj = p.CF >> 6;
+
+    // row r of the tile = pixel (py*8 + r/16, px*16 + r%16); rows outside the picture are computed on a
+    // clamped pixel and never stored
+    auto pixel_of = [&](int r, bool& valid) {
+        const int h = py * PH + (r >> 4), w = px * PW + (r & 15);
+        valid = h < p.H && w < p.W;
+        return min(h, p.H - 1) * p.W + min(w, p.W - 1);
+    };
+
+    const int srow = tid >> 3;                        // 0..63
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const int fsw = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = frow * 128 + (((s * 2 + hi) ^ fsw) << 4);
+
+    {   // WSiLU table -> LDS
+        float4* t = reinterpret_cast<float4*>(smem + TAB_OFF);
+        for (int i = tid; i < WSILU_SEGMENTS; i += NTHREADS) t[i] = p.wsilu[i];
+    }
+    const float4* base_tab = reinterpret_cast<const float4*>(smem + TAB_OFF);
+
+    // ================================================================ phase 0/1 operands
+    // W3, all of it: slab kk = [C rows][64 k] at kk * C*128 inside the (still unused) y1 area
+    for (int kk = 0; kk < nkd; ++kk) {
+#pragma unroll
+        for (int j = 0; j < W3U; ++j) {
+            const half_t* src = p.w3 + static_cast<size_t>(j * 64 + srow) * p.CD + kk * 64 + schunk * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + kk * (C * 128) + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+        }
+    }
+    if constexpr (DW) {
+        // t2 = depthwise 3x3 of t1 (dwconv.hip's arithmetic: fp32 fmaf chain over the in-picture taps
+        // in (ky, kx) order, one rounding to fp16); item = (row, group of 8 channels)
+        const int groups = p.CD >> 3;
+        const half8 zero = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int it = tid; it < BM * groups; it += NTHREADS) {
+            const int r = it / groups, g = it - r * groups;
+            const int h = py * PH + (r >> 4), w = px * PW + (r & 15);
+            half8 o = zero;
+            if (h < p.H && w < p.W) {
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int ih = h + ky - 1;
+                    if (ih < 0 || ih >= p.H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iw = w + kx - 1;
+                        if (iw < 0 || iw >= p.W) continue;
+                        const half8 xv = *reinterpret_cast<const half8*>(p.t1 + (static_cast<size_t>(ih) * p.W + iw) * p.ldt + g * 8);
+                        const half8 wv = *reinterpret_cast<const half8*>(p.dw + (ky * 3 + kx) * p.CD + g * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(static_cast<float>(xv[e]), static_cast<float>(wv[e]), acc[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = to_half(acc[e]);
+            }
+            const int kk = g >> 3, c = g & 7;
+            *reinterpret_cast<half8*>(smem + ST_OFF + kk * SLAB_BYTES + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = o;
+        }
+    } else {
+        // t2 given: straight into the operand slabs
+        for (int kk = 0; kk < nkd; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bool valid;
+                const int m = pixel_of(j * 64 + srow, valid);
+                const half_t* src = p.t1 + static_cast<size_t>(m) * p.ldt + kk * 64 + schunk * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + ST_OFF + kk * SLAB_BYTES + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    }
+
+    // ================================================================ phase 1: y1 = dc.3
+    // accd[nt][mt][r] = channel (wn*NT2 + nt)*32 + 8*(r>>2) + 4*hi + (r&3), row (wm*2 + mt)*32 + frow
+    float16v accd[NT2][2];
+#pragma unroll
+    for (int a = 0; a < NT2; ++a) {
+        float16v init;
+        const half_t* bp = p.b3 + (wn * NT2 + a) * 32 + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) init[4 * g + e] = static_cast<float>(b4[e]);
+        }
+        accd[a][0] = init;
+        accd[a][1] = init;
+    }
+    // the residual of dc.3: 8 consecutive channels of this lane's pixels, straight from global
+    bool rvalid[2];
+    int rpix[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) rpix[mt] = pixel_of((wm * 2 + mt) * 32 + frow, rvalid[mt]);
+    half8 xres[NT2][2][2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+                xres[nt][mt][pr] = *reinterpret_cast<const half8*>(
+                    p.x + static_cast<size_t>(rpix[mt]) * p.ldx + (wn * NT2 + nt) * 32 + 16 * pr + 8 * hi);
+    __syncthreads();                             // W3 + t2 in LDS (vmcnt(0) + barrier)
+    for (int kk = 0; kk < nkd; ++kk) {
+        const char* ts = smem + ST_OFF + kk * SLAB_BYTES + wm * (2 * 32 * 128);
+        const char* ws = smem + kk * (C * 128) + wn * (NT2 * 32 * 128);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            half8 tf[2], wf[NT2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) tf[i] = *reinterpret_cast<const half8*>(ts + i * (32 * 128) + foff[s]);
+#pragma unroll
+            for (int i = 0; i < NT2; ++i) wf[i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s]);
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    accd[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], tf[mt], accd[nt][mt], 0, 0, 0);
+        }
+    }
+    __syncthreads();                             // W3 is dead: the y1 area may be written
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = (wm * 2 + mt) * 32 + frow;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accd[nt][mt][8 * pr + e]),
+                                                                     __float_as_uint(accd[nt][mt][8 * pr + 4 + e]), false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xres[nt][mt][pr][e]));
+                const int cb = (wn * NT2 + nt) * 32 + 16 * pr + 8 * hi;       // channels cb .. cb+7 of y1
+                const int kk = cb >> 6, c = (cb & 63) >> 3;
+                *reinterpret_cast<half8*>(smem + kk * SLAB_BYTES + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = o;
+            }
+    }
+    // (the first barrier of phase 2 makes y1 visible)
+
+    // ================================================================ phase 2: the FFN on the resident y1
+    float16v acc2[NT2][2];
+#pragma unroll
+    for (int a = 0; a < NT2; ++a) {
+        float16v init;
+        const half_t* bp = p.b2 + (wn * NT2 + a) * 32 + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) init[4 * g + e] = static_cast<float>(b4[e]);
+        }
+        acc2[a][0] = init;
+        acc2[a][1] = init;
+    }
+    auto stage_w0 = [&](int buf, int jn, int k0, int part) {
+        char* ws = smem + ST_OFF + buf * WT_BYTES;
+#pragma unroll
+        for (int j = 0; j < WU; ++j) {
+            if (part >= 0 && j != part) continue;
+            const half_t* wsrc = p.w0 + static_cast<size_t>(jn * BNA + j * 64 + srow) * C + k0 + schunk * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(ws + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    for (int jn = 0; jn < nj; ++jn) {
+        stage_w0(0, jn, 0, -1);
+        float16v acc0[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float16v init;
+            const half_t* bp = p.b0 + jn * BNA + (wn * 2 + a) * 32 + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) init[4 * g + e] = static_cast<float>(b4[e]);
+            }
+            acc0[a][0] = init;
+            acc0[a][1] = init;
+        }
+        for (int t = 0; t < NKC; ++t) {
+            __syncthreads();                     // W0 slab t landed, buffer (t+1)&1 is free (and y1 visible)
+            const char* xs = smem + t * SLAB_BYTES + wm * (2 * 32 * 128);
+            const char* ws = smem + ST_OFF + (t & 1) * WT_BYTES + wn * (2 * 32 * 128);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                half8 xf[2], wf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    xf[i] = *reinterpret_cast<const half8*>(xs + i * (32 * 128) + foff[s]);
+                    wf[i] = *reinterpret_cast<const half8*>(ws + i * (32 * 128) + foff[s]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc0[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], xf[mt], acc0[nt][mt], 0, 0, 0);
+                if (t + 1 < NKC) stage_w0((t + 1) & 1, jn, (t + 1) * 64, s);
+            }
+        }
+        __syncthreads();                         // every wave is done with the W0 stages
+#pragma unroll
+        for (int j = 0; j < W2U; ++j) {          // W2 slab [C][64] of this t-tile
+            const half_t* src = p.w2 + static_cast<size_t>(j * 64 + srow) * p.CF + jn * 64 + schunk * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + SLAB2_OFF + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+        }
+        const float4* tab = base_tab;
+        if constexpr (R > 1) {
+            float4* rep = reinterpret_cast<float4*>(smem + REP_OFF);
+            for (int i = tid; i < R * WSILU_SEGMENTS; i += NTHREADS) rep[i] = base_tab[i / R];
+            __syncthreads();
+            tab = rep + (lane & (R - 1));
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {         // T = chunk_add(WSiLU(acc0)) -> fp16 -> LDS (ffn_fused.hip)
+            const int row = (wm * 2 + mt) * 32 + frow;
+            float sum[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float z[16];
+                wsilu16<R>(acc0[h][mt], z, tab);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sum[h][g] = ((z[4 * g] + z[4 * g + 1]) + z[4 * g + 2]) + z[4 * g + 3];
+            }
+            half8 o;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[0][g]), __float_as_uint(sum[1][g]), false, false);
+                o[2 * g] = to_half(__uint_as_float(sw[0]));
+                o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
+            }
+            const int chunk = wn * 2 + hi;
+            *reinterpret_cast<half8*>(smem + ST_OFF + row * 128 + ((chunk ^ (row & 7)) << 4)) = o;
+        }
+        __syncthreads();                         // T complete, W2 slab landed
+        {
+            const char* ws2 = smem + SLAB2_OFF + wn * (NT2 * 32 * 128);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                half8 tf[2], w2f[NT2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int row = (wm * 2 + mt) * 32 + frow;
+                    tf[mt] = *reinterpret_cast<const half8*>(smem + ST_OFF + row * 128 + (((s * 2 + hi) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) w2f[nt] = *reinterpret_cast<const half8*>(ws2 + nt * (32 * 128) + foff[s]);
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc2[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[nt], tf[mt], acc2[nt][mt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                         // T / slab are free again
+    }
+
+    // ================================================================ final: out = acc2 + y1 [+ x] [* q]
+    auto oaddr = [&](int row, int cidx) {        // output tile in the stage area, whole rows
+        return smem + ST_OFF + row * (C * 2) + (((cidx & ~7) | ((cidx & 7) ^ (row & 7))) << 4);
+    };
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = (wm * 2 + mt) * 32 + frow;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc2[nt][mt][8 * pr + e]),
+                                                                     __float_as_uint(acc2[nt][mt][8 * pr + 4 + e]), false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                const int cb = (wn * NT2 + nt) * 32 + 16 * pr + 8 * hi;
+                const int kk = cb >> 6, c = (cb & 63) >> 3;
+                const half8 r8 = *reinterpret_cast<const half8*>(smem + kk * SLAB_BYTES + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
+                if (p.r2x) {     // re-read instead of keeping 32 registers alive through the FFN (x is L2-hot and,
+                                 // when y aliases x, not yet overwritten: this block's stores come last)
+                    const half8 x8 = *reinterpret_cast<const half8*>(p.x + static_cast<size_t>(rpix[mt]) * p.ldx + cb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(x8[e]);
+                }
+                if constexpr (QUANT) {
+                    const half8 q8 = *reinterpret_cast<const half8*>(p.q + cb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
+                }
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                if (p.q2 != nullptr) {
+                    const half8 q8 = *reinterpret_cast<const half8*>(p.q2 + cb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
+                }
+                *reinterpret_cast<half8*>(oaddr(row, cb >> 3)) = o;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < OUNITS; ++j) {
+        const int u = j * NTHREADS + tid;
+        const int row = u / OCH, ch = u % OCH;
+        bool valid;
+        const int m = pixel_of(row, valid);
+        if (valid) {
+            *reinterpret_cast<half8*>(p.y + static_cast<size_t>(m) * p.ldy + ch * 8) = *reinterpret_cast<const half8*>(oaddr(row, ch));
+        }
+    }
+}
+
+template <int NT2, bool DW, bool QUANT>
+void launch(const TailParams& p, hipStream_t stream)
+{
+    auto kern = dcb_tail_kernel<NT2, DW, QUANT>;
+    static bool attr_set = false;
+    constexpr int C = NT2 * 128;
+    constexpr int smem_bytes = (C / 64) * SLAB_BYTES + ST_BYTES + TABLE_BYTES;
+    if (!attr_set) {
+        hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
+                  "hipFuncSetAttribute(dcb_tail)");
+        attr_set = true;
+    }
+    const int grid = ((p.H + PH - 1) / PH) * ((p.W + PW - 1) / PW);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem_bytes, stream, p);
+    hip_check(hipGetLastError(), "dcb_tail launch");
+}
+
+template <int NT2>
+void launch_variant(const TailParams& p, bool dw, hipStream_t stream)
+{
+    const bool quant = p.q != nullptr;
+    if (dw && quant) launch<NT2, true, true>(p, stream);
+    else if (dw) launch<NT2, true, false>(p, stream);
+    else if (quant) launch<NT2, false, true>(p, stream);
+    else launch<NT2, false, false>(p, stream);
+}
+
+bool shape_ok(int c, int cdc, int cffn)
+{
+    return (c == 128 || c == 256) && cdc % 64 == 0 && cdc >= 64 && cdc <= c / 2 && cffn % 64 == 0 && cffn >= 64;
+}
+
+}  // namespace
+
+bool dcb_tail_supported(int H, int W, int c, int cdc, int cffn)
+{
+    // DCVC_DCB_TAIL: 0 = never, 2 = whenever the shape allows (parity tests on small pictures),
+    // unset / 1 = when the patches fill the chip
+    static const int mode = [] { const char* e = getenv("DCVC_DCB_TAIL"); return e != nullptr ? atoi(e) : 1; }();
+    if (mode == 0 || H <= 0 || W <= 0 || !shape_ok(c, cdc, cffn)) return false;
+    const int patches = ((H + PH - 1) / PH) * ((W + PW - 1) / PW);
+    return mode == 2 || patches >= 192;
+}
+
+void dcb_tail(const DcbTailDesc& d, hipStream_t stream)
+{
+    if (!shape_ok(d.c, d.cdc, d.cffn) || d.H <= 0 || d.W <= 0) {
+        throw std::invalid_argument("dcb_tail: unsupported shape (C in {128, 256}, inner widths multiples of 64, C_dc <= C/2)");
+    }
+    if (d.ldt % 8 != 0 || d.ldx % 8 != 0 || d.ldy % 8 != 0) {
+        throw std::invalid_argument("dcb_tail: leading dimensions must be multiples of 8");
+    }
+    TailParams p{};
+    p.t1 = d.t; p.ldt = d.ldt; p.dw = d.dw; p.x = d.x; p.ldx = d.ldx;
+    p.w3 = d.w3; p.b3 = d.b3; p.w0 = d.w0; p.b0 = d.b0; p.w2 = d.w2; p.b2 = d.b2;
+    p.q = d.q; p.q2 = d.q2; p.y = d.y; p.ldy = d.ldy;
+    p.H = d.H; p.W = d.W; p.CD = d.cdc; p.CF = d.cffn; p.r2x = d.shortcut ? 1 : 0;
+    p.wsilu = wsilu_table_device();
+    if (d.c == 128) launch_variant<1>(p, d.dw != nullptr, stream);
+    else launch_variant<2>(p, d.dw != nullptr, stream);
+}
+
+}  // namespace dcvc

@@ -95,6 +95,32 @@ struct FfnFusedDesc {
 bool ffn_fused_supported(int pixels, int c, int cffn);
 void ffn_fused(const FfnFusedDesc& d, hipStream_t stream);
 
+// ---------------------------------------------------------------- DepthConvBlock tail (dcb_tail.hip)
+// Everything of a half-width DepthConvBlock behind dc.0 in one launch (layers_proxy.cpp:79-98):
+//   t2 = depthwise3x3(t) (when dw != null; else t IS t2), y1 = W3 t2 + b3 + x, then the FFN
+//   out = W2 chunk_add(WSiLU(W0 y1 + b0)) + b2 + y1 [+ x when shortcut] [* q], rounded, [* q2].
+// c in {128, 256}, cdc <= c/2 and cffn multiples of 64. Bit-identical to the four-launch sequence.
+// y may alias x; t must not alias y.
+struct DcbTailDesc {
+    const half_t* t = nullptr; int ldt = 0;     // dc.0 output [H*W][ldt] (first cdc channels)
+    const half_t* dw = nullptr;                 // [9][cdc] tap-major depthwise weights, or null
+    const half_t* x = nullptr; int ldx = 0;     // block-internal input (residual of dc.3)
+    const half_t* w3 = nullptr;                 // [c][cdc]
+    const half_t* b3 = nullptr;                 // [c] (depthwise bias folded in)
+    const half_t* w0 = nullptr;                 // [4*cffn][c]
+    const half_t* b0 = nullptr;
+    const half_t* w2 = nullptr;                 // [c][cffn]
+    const half_t* b2 = nullptr;
+    const half_t* q = nullptr;
+    const half_t* q2 = nullptr;
+    half_t* y = nullptr; int ldy = 0;
+    int H = 0, W = 0, c = 0, cdc = 0, cffn = 0;
+    bool shortcut = false;                      // ffn.2 also adds x (block-level shortcut)
+};
+// shape supported AND enough 8x16 patches to fill the chip; DCVC_DCB_TAIL=0 / 2 = never / whenever possible
+bool dcb_tail_supported(int H, int W, int c, int cdc, int cffn);
+void dcb_tail(const DcbTailDesc& d, hipStream_t stream);
+
 // ---------------------------------------------------------------- depthwise 3x3 (dwconv.hip)
 // y[h][w][c] = sum_{ky,kx} x[h+ky-1][w+kx-1][c] * wt[ky][kx][c]   (zero padding, no bias: the
 // reference folds the bias into the next 1x1, layers_proxy.cpp:175-178)

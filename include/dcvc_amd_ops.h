@@ -63,6 +63,16 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
                    const void* r2, int ldr2, const void* q, const void* q2, void* y, int ldy,
                    int pixels, int c, int cffn, void* stream);
 
+/* DepthConvBlockProxy::forward behind dc.0 (layers_proxy.cpp:79-98: d3x3, conv1x1_bias_shortcut,
+ * conv1x1_bias_wsilu_chunk_add, conv1x1_bias_shortcut[2][_with_quant]) in one launch for the
+ * half-width blocks of the inter models: t = dc.0 output [H*W][ldt]; dw = [9][cdc] tap-major depthwise
+ * weights (NULL: t already is the depthwise output); x = block-internal input (residual of dc.3, and
+ * of ffn.2 when shortcut != 0); c in {128, 256}, cdc <= c/2, cffn: multiples of 64. Bit-identical to
+ * the four-launch sequence; y may alias x. */
+int dcvc_dcb_tail(const void* t, int ldt, const void* dw, const void* x, int ldx, const void* w3, const void* b3,
+                  const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                  void* y, int ldy, int H, int W, int c, int cdc, int cffn, int shortcut, void* stream);
+
 /* stream.cu:40-76 / 422-443: y = x * max(q, 0.5) or, with reciprocal != 0, y = x * fp16(1 / max(q, 0.5));
  * q is a tensor of the same shape (the inter models' per-element quantisation step). */
 int dcvc_scale_clamped(const void* x, int ldx, const void* q, int ldq, void* y, int ldy, int pixels,

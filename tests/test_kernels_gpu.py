@@ -414,3 +414,56 @@ def test_ffn_fused_equals_two_launches(ops, P, C, CF, res2, quant, q2, inplace):
         assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
     else:
         assert (ybuf[:, C:] == 9.0).all()
+
+
+@pytest.mark.parametrize("H,W,C,CD,CF,use_dw,shortcut,quant,q2", [
+    (8, 16, 256, 128, 128, True, False, False, False),
+    (13, 37, 256, 128, 128, True, True, False, False),
+    (24, 40, 128, 64, 64, True, False, True, True),
+    (17, 30, 256, 64, 192, False, False, True, False),
+    (136, 240, 256, 128, 128, True, False, False, True),
+    (136, 240, 128, 64, 64, True, True, False, False),
+])
+def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, quant, q2):
+    """depthwise + dc.3 + ffn.0 + ffn.2 in one launch == dwconv3x3, conv1x1(residual),
+    conv1x1(wsilu, chunk_add), conv1x1(residuals, quant) one after the other, bit for bit, on
+    pictures that do and do not divide into 8x16 patches."""
+    from gpu_util import call, ptr, stream
+    dev = "cuda"
+    P = H * W
+    t1 = _rand((P, CD), 1.0, 101).to(dev)
+    dww = _rand((9, CD), 0.4, 102).to(dev)
+    ldx = C + 32
+    xbuf = _rand((P, ldx), 1.0, 103).to(dev)
+    w3 = (_rand((C, CD), 1.0, 104) / CD ** 0.5).half().to(dev)
+    b3 = _rand((C,), 0.3, 105).to(dev)
+    w0 = (_rand((4 * CF, C), 1.0, 106) / C ** 0.5).half().to(dev)
+    b0 = _rand((4 * CF,), 0.3, 107).to(dev)
+    w2 = (_rand((C, CF), 1.0, 108) / CF ** 0.5).half().to(dev)
+    b2 = _rand((C,), 0.3, 109).to(dev)
+    q = (_rand((C,), 0.2, 110) + 1.0).half().to(dev) if quant else None
+    qq = (_rand((C,), 0.2, 111) + 1.0).half().to(dev) if q2 else None
+    if shortcut and quant:
+        pytest.skip("quant with two residuals is not a reference op")
+    # four launches
+    t2 = torch.zeros((P, CD), dtype=torch.half, device=dev)
+    if use_dw:
+        call(ops.dwconv3x3, ptr(t1), CD, ptr(dww), ptr(t2), CD, H, W, CD, stream())
+    else:
+        t2.copy_(t1)
+    y1 = torch.zeros((P, C), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(t2), CD, ptr(w3), ptr(b3), ptr(xbuf), ldx, None, 0, None, None, ptr(y1), C, P, CD, C, 0, stream())
+    t3 = torch.zeros((P, CF), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(y1), C, ptr(w0), ptr(b0), None, 0, None, 0, None, None, ptr(t3), CF, P, C, 4 * CF, 3, stream())
+    want = torch.zeros((P, C), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(t3), CF, ptr(w2), ptr(b2), ptr(y1), C, ptr(xbuf) if shortcut else None, ldx, ptr(q), ptr(qq),
+         ptr(want), C, P, CF, C, 0, stream())
+    torch.cuda.synchronize()
+    # one launch, in place on the block buffer (as the codec runs it)
+    ybuf = xbuf.clone()
+    call(ops.dcb_tail, ptr(t1), CD, ptr(dww) if use_dw else None, ptr(ybuf), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0),
+         ptr(w2), ptr(b2), ptr(q), ptr(qq), ptr(ybuf), ldx, H, W, C, CD, CF, 1 if shortcut else 0, stream())
+    torch.cuda.synchronize()
+    bad = int((ybuf[:, :C] != want).sum())
+    assert bad == 0, "%d of %d outputs differ" % (bad, want.numel())
+    assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
