@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libdcvc_amd.so")
+# DCVC_LIB selects another build of the same library (tuning variants, dcvc_amd/build.py)
+LIB_PATH = os.environ.get("DCVC_LIB") or os.path.join(_PKG, "libdcvc_amd.so")
 
 _lib = None
 

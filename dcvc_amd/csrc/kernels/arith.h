@@ -80,6 +80,15 @@ __device__ __forceinline__ void wsilu16(const float16v& a, float (&z)[16], const
     }
 }
 
+// 16-byte store of a finished output line. (A write-through variant - global_store ... sc0 sc1 -
+// was measured: +2.4 % on the intra bench because the end-of-kernel L2 write-back shrinks, but
+// WRONG at 1080p: a later launch's plain loads can hit a stale line of a reused scratch buffer.
+// Plain stores it is; the pairing rule is sc1 stores AND sc1 loads, MI355X_MICROARCH.md.)
+__device__ __forceinline__ void store_line(half_t* p, half8 v)
+{
+    *reinterpret_cast<half8*>(p) = v;
+}
+
 // C round(): half away from zero (the reference's symbol kernels call round() on a float,
 // elementwise/stream.cu:587-588,873-874).
 __device__ __forceinline__ float round_half_away(float v)

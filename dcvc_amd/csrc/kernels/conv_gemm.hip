@@ -471,8 +471,7 @@ conv_gemm_kernel(const ConvGemmParams p)
             } else {
                 orow = static_cast<size_t>(m);
             }
-            *reinterpret_cast<half8*>(p.y + orow * p.ldy + n0o + ch * 8) =
-                *reinterpret_cast<const half8*>(oaddr(row, ch));
+            store_line(p.y + orow * p.ldy + n0o + ch * 8, *reinterpret_cast<const half8*>(oaddr(row, ch)));
         }
     }
     stamp();                                                       // 12: stores issued

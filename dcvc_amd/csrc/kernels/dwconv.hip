@@ -72,7 +72,7 @@ dwconv3x3_kernel(const half_t* __restrict__ x, int ldx, const half_t* __restrict
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = to_half(acc[e]);
-        *reinterpret_cast<half8*>(y + (static_cast<size_t>(h) * W + w) * ldy + c0) = o;
+        store_line(y + (static_cast<size_t>(h) * W + w) * ldy + c0, o);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             win[0][c] = win[1][c];
