@@ -120,16 +120,18 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
     });
 }
 
-int dcvc_dcb_tail(const void* t, int ldt, const void* dw, const void* x, int ldx, const void* w3, const void* b3,
+int dcvc_dcb_tail(const void* w1, const void* b1, const void* t, int ldt, const void* dw, const void* x, int ldx,
+                  const void* w3, const void* b3,
                   const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
                   void* y, int ldy, int Hh, int W, int c, int cdc, int cffn, int shortcut, void* stream)
 {
     return dcvc::guarded([&] {
         dcvc::kernels_init();
         dcvc::DcbTailDesc d;
-        d.t = H(t); d.ldt = ldt; d.dw = H(dw); d.x = H(x); d.ldx = ldx; d.w3 = H(w3); d.b3 = H(b3);
+        d.w1 = H(w1); d.b1 = H(b1); d.t = H(t); d.ldt = ldt; d.dw = H(dw); d.x = H(x); d.ldx = ldx; d.w3 = H(w3); d.b3 = H(b3);
         d.w0 = H(w0); d.b0 = H(b0); d.w2 = H(w2); d.b2 = H(b2); d.q = H(q); d.q2 = H(q2);
         d.y = H(y); d.ldy = ldy; d.H = Hh; d.W = W; d.c = c; d.cdc = cdc; d.cffn = cffn; d.shortcut = shortcut != 0;
+        if (d.w1 != nullptr && d.x == d.y) throw std::invalid_argument("dcb_tail with dc.0 inside cannot run in place");
         dcvc::dcb_tail(d, S(stream));
     });
 }
@@ -207,6 +209,11 @@ int dcvc_mask_step_dec(const void* decoded, const void* cond, const void* block_
         d.y_hat = H(y_hat); d.ldh = ldh; d.H = Hh; d.W = W; d.C = C; d.nsteps = nsteps; d.step = step;
         dcvc::mask_step_dec(d, S(stream));
     });
+}
+
+int dcvc_dcb_tail_debug_buffer(void* device_buffer)
+{
+    return dcvc::guarded([&] { dcvc::dcb_tail_debug_buffer(static_cast<dcvc::half_t*>(device_buffer)); });
 }
 
 int dcvc_gemm_timeline_buffer(void* device_buffer)

@@ -99,7 +99,8 @@ private:
     half_t* m_FI = nullptr;      // [P8][192]  reference feature: unshuffled I picture / recon-head output
     half_t* m_CATM = nullptr;    // [P8][512]  memory | feature_p          (feature_adaptor_m input)
     half_t* m_CATD = nullptr;    // [P8][512]  decoder.up out (x unshuffled at 64:256) | ctx
-    half_t* m_T = nullptr;       // [P8][256]  chain temporary
+    half_t* m_T = nullptr;       // [P8][256]  chain temporaries (the blocks ping-pong between the two)
+    half_t* m_T2 = nullptr;
     half_t *m_Y = nullptr, *m_Ypad = nullptr;
     half_t *m_Z1 = nullptr, *m_Z2 = nullptr, *m_Z3 = nullptr, *m_ZH = nullptr;
     int8_t* m_ZI8 = nullptr;

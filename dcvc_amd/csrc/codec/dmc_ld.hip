@@ -103,7 +103,7 @@ void DmcLdCodec::prepare(int height, int width)
     m_FI = H(P8 * kChSrc);
     m_CATM = H(P8 * (kChM + kChD));
     m_CATD = H(P8 * (kChD + kChM));
-    m_T = H(P8 * kChM);
+    m_T = H(P8 * kChM); m_T2 = H(P8 * kChM);
     m_Y = H(P16 * kChY); m_Ypad = g.padded() ? H(P16p * kChY) : m_Y;
     m_Z1 = H(P16p * kChZ); m_Z2 = H(P32 * kChZ); m_Z3 = H(P64 * kChZ); m_ZH = H(P64 * kChZ);
     m_ZI8 = static_cast<int8_t*>(m_bmem.alloc(P64 * kChZ));
@@ -137,40 +137,25 @@ void DmcLdCodec::select_qp(int qp, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------ networks
-namespace {
-
-// x -> (first block) -> tmp -> ... in place ... -> (last block) -> y
-void run_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, int W, const Scratch& s,
-               hipStream_t st, const half_t* q_fused_last = nullptr)
-{
-    View cur = x;
-    for (int i = 0; i < n; ++i) {
-        const View out = (i == n - 1) ? y : tmp;
-        blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr);
-        cur = out;
-    }
-}
-
-}  // namespace
-
 void DmcLdCodec::run_fa_i(hipStream_t st)
 {
     const View t(m_T, kChM, kChM);
-    run_chain(m_fa_i, 4, View(m_FI, kChSrc, kChSrc), t, View(m_CATM, kChM + kChD, kChM), m_g.H8, m_g.W8, m_s, st);
+    run_dcb_chain(m_fa_i, 4, View(m_FI, kChSrc, kChSrc), t, View(m_CATM, kChM + kChD, kChM), m_g.H8, m_g.W8, m_s, st,
+                  nullptr, View(m_T2, kChM, kChM));
 }
 
 void DmcLdCodec::run_fa_m(hipStream_t st)
 {
     const View t(m_T, kChM, kChM);
-    run_chain(m_fa_m, 4, View(m_CATM, kChM + kChD, kChM + kChD), t, View(m_CATM, kChM + kChD, kChM),
-              m_g.H8, m_g.W8, m_s, st);
+    run_dcb_chain(m_fa_m, 4, View(m_CATM, kChM + kChD, kChM + kChD), t, View(m_CATM, kChM + kChD, kChM),
+                  m_g.H8, m_g.W8, m_s, st, nullptr, View(m_T2, kChM, kChM));
 }
 
 void DmcLdCodec::run_fe(hipStream_t st)
 {
     const View t(m_T, kChM, kChM);
-    run_chain(m_fe, 5, View(m_CATM, kChM + kChD, kChM), t, View(m_CATD + kChD, kChD + kChM, kChM),
-              m_g.H8, m_g.W8, m_s, st);
+    run_dcb_chain(m_fe, 5, View(m_CATM, kChM + kChD, kChM), t, View(m_CATD + kChD, kChD + kChM, kChM),
+                  m_g.H8, m_g.W8, m_s, st, nullptr, View(m_T2, kChM, kChM));
 }
 
 void DmcLdCodec::run_tpe(hipStream_t st)
@@ -184,7 +169,8 @@ void DmcLdCodec::run_encoder(hipStream_t st)
     const Geometry& g = m_g;
     const View t(m_T, kChD, kChD);
     // [x unshuffled | ctx] = channels 64..511 of CATD (dmc_ld_proxy.cpp:755-757)
-    run_chain(m_enc1, 2, View(m_CATD + 64, kChD + kChM, kChSrc + kChM), t, t, g.H8, g.W8, m_s, st);
+    run_dcb_chain(m_enc1, 2, View(m_CATD + 64, kChD + kChM, kChSrc + kChM), t, t, g.H8, g.W8, m_s, st, nullptr,
+                  View(m_T2, kChD, kChD));
     m_enc2.forward(t, t, g.H8, g.W8, m_s, st, false, m_cur_q_encoder);
     ConvKxKDesc d;
     d.x = m_T; d.ldx = kChD; d.w = m_enc_down.w; d.bias = m_enc_down.b; d.zeros = m_zeros;
@@ -241,7 +227,8 @@ void DmcLdCodec::run_decoder(hipStream_t st)
     const Geometry& g = m_g;
     m_dec_up.forward(View(m_CATSP, 4 * kChY, kChY), View(m_CATD, kChD + kChM, kChD), g.H16, g.W16, st);
     const View t(m_T, kChD, kChD);
-    run_chain(m_dec1, 3, View(m_CATD, kChD + kChM, kChD + kChM), t, t, g.H8, g.W8, m_s, st);
+    run_dcb_chain(m_dec1, 3, View(m_CATD, kChD + kChM, kChD + kChM), t, t, g.H8, g.W8, m_s, st, nullptr,
+                  View(m_T2, kChD, kChD));
     Conv1x1Desc d;      // conv1x1_bias_with_quant -> feature_p, second half of the adaptor_m input
     d.x = m_T; d.ldx = kChD; d.w = m_dec2.w; d.bias = m_dec2.b; d.q = m_cur_q_decoder;
     d.y = m_CATM + kChM; d.ldy = kChM + kChD; d.pixels = g.P8(); d.cin = kChD; d.cout = kChD;
@@ -252,7 +239,8 @@ void DmcLdCodec::run_recon_head(half_t* x_hat, hipStream_t st)
 {
     const Geometry& g = m_g;
     const View t(m_T, kChD, kChD);
-    run_chain(m_rh, 3, View(m_CATM + kChM, kChM + kChD, kChD), t, t, g.H8, g.W8, m_s, st);
+    run_dcb_chain(m_rh, 3, View(m_CATM + kChM, kChM + kChD, kChD), t, t, g.H8, g.W8, m_s, st, nullptr,
+                  View(m_T2, kChD, kChD));
     Conv1x1Desc d;      // the head output doubles as the reference feature after a reset
     d.x = m_T; d.ldx = kChD; d.w = m_rh_head.w; d.bias = m_rh_head.b;
     d.y = m_FI; d.ldy = kChSrc; d.pixels = g.P8(); d.cin = kChD; d.cout = kChSrc;

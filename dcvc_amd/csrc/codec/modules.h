@@ -91,9 +91,12 @@ struct DcbW {
     int cdc = 0;            // depthwise width (c or c/2)
     int cffn = 0;           // ffn inner width after chunk-add (c or c/2)
     void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
-    // y may alias x only when the block has no adaptor and `shortcut` is false
+    // y may alias x only when the block has no adaptor and `shortcut` is false. `alt`: a spare
+    // [pixels][c] buffer for the adaptor output; with it (or without an adaptor) and y != x the
+    // half-width blocks of the inter models run as ONE launch (kernels/dcb_tail.hip reads the block
+    // input of neighbouring patches, so it cannot run in place)
     void forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut = false,
-                 const half_t* q_fused = nullptr, const half_t* q_after = nullptr) const;
+                 const half_t* q_fused = nullptr, const half_t* q_after = nullptr, View alt = View()) const;
 };
 
 // layers.py:176-188: pixel_unshuffle(2) + 1x1 == 2x2 stride-2 conv (layers_proxy.cpp:263-264)
@@ -140,11 +143,16 @@ struct DcbChain {
     std::vector<DcbW> blocks;
     void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
     // x -> (first block) -> tmp -> ... in place ... -> (last block) -> y; q_fused_last: scale fused
-    // into the last block (DepthConvBlockProxy::forward(x, quant), layers_proxy.cpp:92-95)
+    // into the last block (DepthConvBlockProxy::forward(x, quant), layers_proxy.cpp:92-95).
+    // With a second temporary the blocks ping-pong between the two instead of running in place.
     void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
-                 const half_t* q_fused_last = nullptr) const;
+                 const half_t* q_fused_last = nullptr, View tmp2 = View()) const;
     size_t size() const { return blocks.size(); }
 };
+
+// the same launch sequence over a plain array of blocks (codecs that keep DcbW[n] members)
+void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, int W, const Scratch& s,
+                   hipStream_t st, const half_t* q_fused_last = nullptr, View tmp2 = View());
 
 // dense k x k conv weight in tap-major layout
 struct ConvKW {

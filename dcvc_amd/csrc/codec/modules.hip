@@ -159,7 +159,7 @@ void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
 }
 
 void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut,
-                   const half_t* q_fused, const half_t* q_after) const
+                   const half_t* q_fused, const half_t* q_after, View alt) const
 {
     const int P = H * W;
     if (static_cast<size_t>(P) * cdc > s.elems || static_cast<size_t>(P) * cffn > s.elems) {
@@ -171,23 +171,28 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         throw std::invalid_argument("DepthConvBlock with adaptor and shortcut is not a DCVC-UF block");
     }
     if (has_adaptor) {
+        const View a = (alt.p != nullptr && alt.p != y.p) ? View(alt.p, alt.ld, c) : y;
         Conv1x1Desc d;
         d.x = x.p; d.ldx = x.ld; d.w = adaptor.w; d.bias = adaptor.b;
-        d.y = y.p; d.ldy = y.ld; d.pixels = P; d.cin = adaptor.cin; d.cout = adaptor.cout;
+        d.y = a.p; d.ldy = a.ld; d.pixels = P; d.cin = adaptor.cin; d.cout = adaptor.cout;
         conv1x1(d, st);
-        in = y;
+        in = a;
     } else if (shortcut && x.p == y.p) {
         throw std::invalid_argument("DepthConvBlock with shortcut cannot run in place");
     }
-    {   // dc.0 + WSiLU
+    const bool tail = dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr &&
+                      dc3.b != nullptr && dc0.b != nullptr;
+    const bool tail_dc0 = tail && dcb_tail_takes_dc0() && in.p != y.p;      // reads neighbours' input: not in place
+    if (!tail_dc0) {   // dc.0 + WSiLU
         Conv1x1Desc d;
         d.x = in.p; d.ldx = in.ld; d.w = dc0.w; d.bias = dc0.b; d.wsilu = true;
         d.y = s.t1; d.ldy = cdc; d.pixels = P; d.cin = c; d.cout = cdc;
         conv1x1(d, st);
     }
-    if (dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr && dc3.b != nullptr) {
-        // depthwise + dc.3 + ffn.0 + ffn.2 in one launch (kernels/dcb_tail.hip)
+    if (tail) {
+        // [dc.0 +] depthwise + dc.3 + ffn.0 + ffn.2 in one launch (kernels/dcb_tail.hip)
         DcbTailDesc d;
+        if (tail_dc0) { d.w1 = dc0.w; d.b1 = dc0.b; }
         d.t = s.t1; d.ldt = cdc; d.dw = dw; d.x = in.p; d.ldx = in.ld;
         d.w3 = dc3.w; d.b3 = dc3.b; d.w0 = ffn0.w; d.b0 = ffn0.b; d.w2 = ffn2.w; d.b2 = ffn2.b;
         d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld;
@@ -331,16 +336,40 @@ void DcbChain::load(const ParamStore& ps, DeviceArena& mem, const std::string& p
     if (blocks.empty()) throw std::invalid_argument("no DepthConvBlocks under " + prefix);
 }
 
-void DcbChain::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
-                       const half_t* q_fused_last) const
+void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, int W, const Scratch& s,
+                   hipStream_t st, const half_t* q_fused_last, View tmp2)
 {
+    if (tmp2.p == nullptr) {
+        View cur = x;
+        for (int i = 0; i < n; ++i) {
+            const View out = (i == n - 1) ? y : tmp;
+            blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr);
+            cur = out;
+        }
+        return;
+    }
+    // ping-pong: out[n-1] = y, the outputs before it alternate between the two temporaries so that no
+    // block runs in place (the one-launch block kernel needs input != output)
+    const View a = tmp, b = tmp2;
     View cur = x;
-    const int n = static_cast<int>(blocks.size());
     for (int i = 0; i < n; ++i) {
-        const View out = (i == n - 1) ? y : tmp;
-        blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr);
+        View out = y;
+        if (i != n - 1) {
+            const bool y_is_a = y.p == a.p;
+            const int back = n - 1 - i;                         // distance from the last block
+            out = (back % 2 == 1) ? (y_is_a ? b : a) : (y_is_a ? a : b);
+        }
+        const View spare = (out.p == a.p) ? b : a;              // for an adaptor: neither input nor output
+        blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr, nullptr,
+                          cur.p == spare.p ? View() : spare);
         cur = out;
     }
+}
+
+void DcbChain::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
+                       const half_t* q_fused_last, View tmp2) const
+{
+    run_dcb_chain(blocks.data(), static_cast<int>(blocks.size()), x, tmp, y, H, W, s, st, q_fused_last, tmp2);
 }
 
 }  // namespace dcvc

@@ -101,6 +101,11 @@ __device__ __forceinline__ float round_half_away(float v)
 
 __device__ __forceinline__ half_t to_half(float v)
 {
+    // The empty asm makes `v` opaque: without it hipcc contracts (half)(a * b) into ONE
+    // v_fma_mixlo_f16, which rounds the exact product straight to fp16 - a single rounding where the
+    // arithmetic policy (and the oracle) have two, fp32 then fp16. Measured on MI355X
+    // (tools/probes/mixlo_probe.hip): 973 of 16.7 M random products differ by one fp16 ulp.
+    asm("" : "+v"(v));
     return static_cast<half_t>(v);   // v_cvt_f16_f32, round-to-nearest-even, subnormals kept
 }
 

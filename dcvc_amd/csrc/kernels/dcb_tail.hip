@@ -45,6 +45,8 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct TailParams {
+    const half_t* w1;     // dc.0 weights [CD][C] and bias [CD] (DC0 only: dc.0 runs inside the launch)
+    const half_t* b1;
     const half_t* t1;     // dc.0 output [H*W][ldt], first CD channels (DW) / dc.2 output (no DW)
     const half_t* dw;     // depthwise weights [9][CD] (DW only)
     const half_t* x;      // block-internal input [H*W][ldx]: residual of dc.3 (and of ffn.2 when `r2x`)
@@ -61,12 +63,20 @@ struct TailParams {
     int ldt, ldx, ldy;
     int H, W, CD, CF;
     int r2x;              // ffn.2's second residual = x (block-level shortcut)
+    half_t* dbg_t1;       // debugging aid: dc.0 output of the patch pixels [H*W][CD], or null
 };
 
-template <int NT2, bool DW, bool QUANT>
+// DC0: dc.0 (1x1 + WSiLU) runs inside the launch too, on the 10 x 18 halo tile of the patch (192 rows
+// with padding: 1.4x the patch, dc.0 is the cheapest conv of the block), its output stays in LDS for
+// the depthwise: the whole DepthConvBlock behind an optional adaptor is ONE launch.
+template <int NT2, bool DW, bool QUANT, bool DC0>
 __global__ void __launch_bounds__(NTHREADS)
 dcb_tail_kernel(const TailParams p)
 {
+    static_assert(!DC0 || DW, "dc.0 inside the launch feeds the depthwise");
+    constexpr int HW_ = PW + 2;                      // halo tile: 10 x 18 pixels
+    constexpr int HROWS = 192;                       // padded to 6 MFMA row tiles
+    constexpr int XH_BYTES = HROWS * 128;            // halo activation slab [192][64]: 24 KB
     constexpr int C = NT2 * 128;
     constexpr int NKC = C / 64;                      // operand slabs of y1
     constexpr int Y1_BYTES = NKC * SLAB_BYTES;       // 64 KB (C = 256) / 32 KB (C = 128)
@@ -119,14 +129,116 @@ dcb_tail_kernel(const TailParams p)
     }
     const float4* base_tab = reinterpret_cast<const float4*>(smem + TAB_OFF);
 
-    // ================================================================ phase 0/1 operands
-    // W3, all of it: slab kk = [C rows][64 k] at kk * C*128 inside the (still unused) y1 area
-    for (int kk = 0; kk < nkd; ++kk) {
+    // where phase 0/1 keep their operands: W3 slabs and t2 slabs swap places when dc.0 runs inside
+    constexpr int W3_BASE = DC0 ? ST_OFF : 0;
+    constexpr int T2_BASE = DC0 ? 0 : ST_OFF;
+    auto load_w3 = [&]() {        // W3, all of it: slab kk = [C rows][64 k] at W3_BASE + kk * C*128
+        for (int kk = 0; kk < nkd; ++kk) {
 #pragma unroll
-        for (int j = 0; j < W3U; ++j) {
-            const half_t* src = p.w3 + static_cast<size_t>(j * 64 + srow) * p.CD + kk * 64 + schunk * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + kk * (C * 128) + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+            for (int j = 0; j < W3U; ++j) {
+                const half_t* src = p.w3 + static_cast<size_t>(j * 64 + srow) * p.CD + kk * 64 + schunk * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + W3_BASE + kk * (C * 128) + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+            }
         }
+    };
+
+    if constexpr (DC0) {
+        // ============================================================ phase -1: t1 = WSiLU(W1 x + b1) on the halo tile
+        // W1, all of it, in the (still unused) y1 area: slab kk = [CD rows][64 k] at kk * CD*128
+        const int w1u = p.CD * 8 / NTHREADS;         // CD = 64 -> 1, 128 -> 2
+        for (int kk = 0; kk < NKC; ++kk)
+            for (int j = 0; j < w1u; ++j) {
+                const half_t* src = p.w1 + static_cast<size_t>(j * 64 + srow) * C + kk * 64 + schunk * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + kk * (p.CD * 128) + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+            }
+        // halo row r -> pixel (py*8 - 1 + r/18, px*16 - 1 + r%18), clamped for the address
+        const half_t* hsrc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int r = min(j * 64 + srow, (PH + 2) * HW_ - 1);
+            const int hh = min(max(py * PH - 1 + r / HW_, 0), p.H - 1), ww = min(max(px * PW - 1 + r % HW_, 0), p.W - 1);
+            hsrc[j] = p.x + (static_cast<size_t>(hh) * p.W + ww) * p.ldx + schunk * 8;
+        }
+        auto stage_x = [&](int buf, int k0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(hsrc[j] + k0), (lptr_t)(smem + ST_OFF + buf * XH_BYTES + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+        };
+        stage_x(0, 0);
+        // acc1[mt][r]: channel wn*32 + 8*(r>>2) + 4*hi + (r&3) of t1, halo row (wm*3 + mt)*32 + frow
+        const bool wave_on = wn * 32 < p.CD;
+        float16v acc1[3];
+        {
+            float16v init;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) init[r] = 0.f;
+            if (wave_on) {
+                const half_t* bp = p.b1 + wn * 32 + 4 * hi;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) init[4 * g + e] = static_cast<float>(b4[e]);
+                }
+            }
+            acc1[0] = acc1[1] = acc1[2] = init;
+        }
+        for (int t = 0; t < NKC; ++t) {
+            __syncthreads();                         // slab t (and W1) landed, the other buffer is free
+            if (t + 1 < NKC) stage_x((t + 1) & 1, (t + 1) * 64);
+            if (wave_on) {
+                const char* xs = smem + ST_OFF + (t & 1) * XH_BYTES + wm * (3 * 32 * 128);
+                const char* ws = smem + t * (p.CD * 128) + wn * (32 * 128);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const half8 wf = *reinterpret_cast<const half8*>(ws + foff[s]);
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) {
+                        const half8 xf = *reinterpret_cast<const half8*>(xs + mt * (32 * 128) + foff[s]);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc1[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                             // stage area free: t1 [192][CD] goes there, row-major
+        if (wave_on) {
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                const int r = (wm * 3 + mt) * 32 + frow;
+                const int hh = py * PH - 1 + r / HW_, ww = px * PW - 1 + r % HW_;
+                const bool inside = r < (PH + 2) * HW_ && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc1[mt][8 * pr + e]),
+                                                                         __float_as_uint(acc1[mt][8 * pr + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw[0]);
+                        v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    wsilu8<1>(v, base_tab);
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = inside ? to_half(v[e]) : static_cast<half_t>(0.f);   // zero padding of the depthwise
+                    *reinterpret_cast<half8*>(smem + ST_OFF + r * (p.CD * 2) + (wn * 32 + 16 * pr + 8 * hi) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();                             // t1 complete; W1 is dead
+        if (p.dbg_t1 != nullptr) {
+            for (int it = tid; it < BM * (p.CD >> 3); it += NTHREADS) {
+                const int r = it / (p.CD >> 3), g = it - r * (p.CD >> 3);
+                const int h = py * PH + (r >> 4), w = px * PW + (r & 15);
+                if (h < p.H && w < p.W) {
+                    const int hr = ((r >> 4) + 1) * HW_ + (r & 15) + 1;
+                    *reinterpret_cast<half8*>(p.dbg_t1 + (static_cast<size_t>(h) * p.W + w) * p.CD + g * 8) =
+                        *reinterpret_cast<const half8*>(smem + ST_OFF + hr * (p.CD * 2) + g * 16);
+                }
+            }
+        }
+    } else {
+        load_w3();
     }
     if constexpr (DW) {
         // t2 = depthwise 3x3 of t1 (dwconv.hip's arithmetic: fp32 fmaf chain over the in-picture taps
@@ -149,7 +261,13 @@ dcb_tail_kernel(const TailParams p)
                     for (int kx = 0; kx < 3; ++kx) {
                         const int iw = w + kx - 1;
                         if (iw < 0 || iw >= p.W) continue;
-                        const half8 xv = *reinterpret_cast<const half8*>(p.t1 + (static_cast<size_t>(ih) * p.W + iw) * p.ldt + g * 8);
+                        half8 xv;
+                        if constexpr (DC0) {
+                            const int hr = ((r >> 4) + ky) * HW_ + (r & 15) + kx;       // halo row of this tap
+                            xv = *reinterpret_cast<const half8*>(smem + ST_OFF + hr * (p.CD * 2) + g * 16);
+                        } else {
+                            xv = *reinterpret_cast<const half8*>(p.t1 + (static_cast<size_t>(ih) * p.W + iw) * p.ldt + g * 8);
+                        }
                         const half8 wv = *reinterpret_cast<const half8*>(p.dw + (ky * 3 + kx) * p.CD + g * 8);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc[e] = fmaf(static_cast<float>(xv[e]), static_cast<float>(wv[e]), acc[e]);
@@ -159,7 +277,11 @@ dcb_tail_kernel(const TailParams p)
                 for (int e = 0; e < 8; ++e) o[e] = to_half(acc[e]);
             }
             const int kk = g >> 3, c = g & 7;
-            *reinterpret_cast<half8*>(smem + ST_OFF + kk * SLAB_BYTES + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = o;
+            *reinterpret_cast<half8*>(smem + T2_BASE + kk * SLAB_BYTES + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = o;
+        }
+        if constexpr (DC0) {
+            __syncthreads();                         // t1 is dead: W3 may take the stage area
+            load_w3();
         }
     } else {
         // t2 given: straight into the operand slabs
@@ -169,7 +291,7 @@ dcb_tail_kernel(const TailParams p)
                 bool valid;
                 const int m = pixel_of(j * 64 + srow, valid);
                 const half_t* src = p.t1 + static_cast<size_t>(m) * p.ldt + kk * 64 + schunk * 8;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + ST_OFF + kk * SLAB_BYTES + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + T2_BASE + kk * SLAB_BYTES + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
             }
         }
     }
@@ -206,8 +328,8 @@ dcb_tail_kernel(const TailParams p)
                     p.x + static_cast<size_t>(rpix[mt]) * p.ldx + (wn * NT2 + nt) * 32 + 16 * pr + 8 * hi);
     __syncthreads();                             // W3 + t2 in LDS (vmcnt(0) + barrier)
     for (int kk = 0; kk < nkd; ++kk) {
-        const char* ts = smem + ST_OFF + kk * SLAB_BYTES + wm * (2 * 32 * 128);
-        const char* ws = smem + kk * (C * 128) + wn * (NT2 * 32 * 128);
+        const char* ts = smem + T2_BASE + kk * SLAB_BYTES + wm * (2 * 32 * 128);
+        const char* ws = smem + W3_BASE + kk * (C * 128) + wn * (NT2 * 32 * 128);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             half8 tf[2], wf[NT2];
@@ -222,7 +344,7 @@ dcb_tail_kernel(const TailParams p)
                     accd[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], tf[mt], accd[nt][mt], 0, 0, 0);
         }
     }
-    __syncthreads();                             // W3 is dead: the y1 area may be written
+    __syncthreads();                             // W3 / t2 are dead: the y1 area may be written
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int row = (wm * 2 + mt) * 32 + frow;
@@ -424,10 +546,10 @@ dcb_tail_kernel(const TailParams p)
     }
 }
 
-template <int NT2, bool DW, bool QUANT>
+template <int NT2, bool DW, bool QUANT, bool DC0>
 void launch(const TailParams& p, hipStream_t stream)
 {
-    auto kern = dcb_tail_kernel<NT2, DW, QUANT>;
+    auto kern = dcb_tail_kernel<NT2, DW, QUANT, DC0>;
     static bool attr_set = false;
     constexpr int C = NT2 * 128;
     constexpr int smem_bytes = (C / 64) * SLAB_BYTES + ST_BYTES + TABLE_BYTES;
@@ -444,11 +566,14 @@ void launch(const TailParams& p, hipStream_t stream)
 template <int NT2>
 void launch_variant(const TailParams& p, bool dw, hipStream_t stream)
 {
-    const bool quant = p.q != nullptr;
-    if (dw && quant) launch<NT2, true, true>(p, stream);
-    else if (dw) launch<NT2, true, false>(p, stream);
-    else if (quant) launch<NT2, false, true>(p, stream);
-    else launch<NT2, false, false>(p, stream);
+    const bool quant = p.q != nullptr, dc0 = p.w1 != nullptr;
+    if (dc0 && !dw) throw std::invalid_argument("dcb_tail: dc.0 inside the launch needs the depthwise weights");
+    if (dc0 && quant) launch<NT2, true, true, true>(p, stream);
+    else if (dc0) launch<NT2, true, false, true>(p, stream);
+    else if (dw && quant) launch<NT2, true, true, false>(p, stream);
+    else if (dw) launch<NT2, true, false, false>(p, stream);
+    else if (quant) launch<NT2, false, true, false>(p, stream);
+    else launch<NT2, false, false, false>(p, stream);
 }
 
 bool shape_ok(int c, int cdc, int cffn)
@@ -456,16 +581,29 @@ bool shape_ok(int c, int cdc, int cffn)
     return (c == 128 || c == 256) && cdc % 64 == 0 && cdc >= 64 && cdc <= c / 2 && cffn % 64 == 0 && cffn >= 64;
 }
 
+half_t* g_dbg_t1 = nullptr;
+
 }  // namespace
+
+void dcb_tail_debug_buffer(half_t* device_buffer)
+{
+    g_dbg_t1 = device_buffer;
+}
 
 bool dcb_tail_supported(int H, int W, int c, int cdc, int cffn)
 {
     // DCVC_DCB_TAIL: 0 = never, 2 = whenever the shape allows (parity tests on small pictures),
-    // unset / 1 = when the patches fill the chip
+    // unset / 1 = when the patches fill the chip, 3 = like 1 but dc.0 stays a launch of its own (A/B)
     static const int mode = [] { const char* e = getenv("DCVC_DCB_TAIL"); return e != nullptr ? atoi(e) : 1; }();
     if (mode == 0 || H <= 0 || W <= 0 || !shape_ok(c, cdc, cffn)) return false;
     const int patches = ((H + PH - 1) / PH) * ((W + PW - 1) / PW);
     return mode == 2 || patches >= 192;
+}
+
+bool dcb_tail_takes_dc0()
+{
+    static const int mode = [] { const char* e = getenv("DCVC_DCB_TAIL"); return e != nullptr ? atoi(e) : 1; }();
+    return mode != 3;
 }
 
 void dcb_tail(const DcbTailDesc& d, hipStream_t stream)
@@ -477,11 +615,13 @@ void dcb_tail(const DcbTailDesc& d, hipStream_t stream)
         throw std::invalid_argument("dcb_tail: leading dimensions must be multiples of 8");
     }
     TailParams p{};
-    p.t1 = d.t; p.ldt = d.ldt; p.dw = d.dw; p.x = d.x; p.ldx = d.ldx;
+    p.t1 = d.t; p.ldt = d.ldt; p.dw = d.dw; p.x = d.x; p.ldx = d.ldx; p.w1 = d.w1; p.b1 = d.b1;
+    if (d.w1 == nullptr && d.t == nullptr) throw std::invalid_argument("dcb_tail: either the dc.0 output or its weights");
     p.w3 = d.w3; p.b3 = d.b3; p.w0 = d.w0; p.b0 = d.b0; p.w2 = d.w2; p.b2 = d.b2;
     p.q = d.q; p.q2 = d.q2; p.y = d.y; p.ldy = d.ldy;
     p.H = d.H; p.W = d.W; p.CD = d.cdc; p.CF = d.cffn; p.r2x = d.shortcut ? 1 : 0;
     p.wsilu = wsilu_table_device();
+    p.dbg_t1 = g_dbg_t1;
     if (d.c == 128) launch_variant<1>(p, d.dw != nullptr, stream);
     else launch_variant<2>(p, d.dw != nullptr, stream);
 }

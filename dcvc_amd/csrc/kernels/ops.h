@@ -102,6 +102,8 @@ void ffn_fused(const FfnFusedDesc& d, hipStream_t stream);
 // c in {128, 256}, cdc <= c/2 and cffn multiples of 64. Bit-identical to the four-launch sequence.
 // y may alias x; t must not alias y.
 struct DcbTailDesc {
+    const half_t* w1 = nullptr;                 // dc.0 weights [cdc][c] + bias [cdc]: when given (with dw), dc.0 (1x1 +
+    const half_t* b1 = nullptr;                 //   WSiLU on x) runs inside the launch as well and `t` is not read
     const half_t* t = nullptr; int ldt = 0;     // dc.0 output [H*W][ldt] (first cdc channels)
     const half_t* dw = nullptr;                 // [9][cdc] tap-major depthwise weights, or null
     const half_t* x = nullptr; int ldx = 0;     // block-internal input (residual of dc.3)
@@ -119,7 +121,11 @@ struct DcbTailDesc {
 };
 // shape supported AND enough 8x16 patches to fill the chip; DCVC_DCB_TAIL=0 / 2 = never / whenever possible
 bool dcb_tail_supported(int H, int W, int c, int cdc, int cffn);
+bool dcb_tail_takes_dc0();       // false only for A/B measurements (DCVC_DCB_TAIL=3)
 void dcb_tail(const DcbTailDesc& d, hipStream_t stream);
+// debugging aid: when non-null, launches with dc.0 inside also write dc.0's output of every pixel
+// ([H*W][cdc]) to this device buffer
+void dcb_tail_debug_buffer(half_t* device_buffer);
 
 // ---------------------------------------------------------------- depthwise 3x3 (dwconv.hip)
 // y[h][w][c] = sum_{ky,kx} x[h+ky-1][w+kx-1][c] * wt[ky][kx][c]   (zero padding, no bias: the

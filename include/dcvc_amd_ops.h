@@ -68,10 +68,17 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
  * half-width blocks of the inter models: t = dc.0 output [H*W][ldt]; dw = [9][cdc] tap-major depthwise
  * weights (NULL: t already is the depthwise output); x = block-internal input (residual of dc.3, and
  * of ffn.2 when shortcut != 0); c in {128, 256}, cdc <= c/2, cffn: multiples of 64. Bit-identical to
- * the four-launch sequence; y may alias x. */
-int dcvc_dcb_tail(const void* t, int ldt, const void* dw, const void* x, int ldx, const void* w3, const void* b3,
+ * the four-launch sequence; y may alias x. With w1 / b1 (dc.0 weights [cdc][c] and bias) non-NULL, dc.0
+ * (conv1x1_bias_wsilu on x) runs inside the launch too and t is not read - the whole block behind an
+ * optional adaptor in one launch; y must then NOT alias x (patches read their neighbours' input). */
+int dcvc_dcb_tail(const void* w1, const void* b1, const void* t, int ldt, const void* dw, const void* x, int ldx,
+                  const void* w3, const void* b3,
                   const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
                   void* y, int ldy, int H, int W, int c, int cdc, int cffn, int shortcut, void* stream);
+
+/* Debugging aid (no reference counterpart): device buffer [H*W][cdc] that receives dc.0's output from
+ * the following dcvc_dcb_tail launches with dc.0 inside; NULL = off. */
+int dcvc_dcb_tail_debug_buffer(void* device_buffer);
 
 /* stream.cu:40-76 / 422-443: y = x * max(q, 0.5) or, with reciprocal != 0, y = x * fp16(1 / max(q, 0.5));
  * q is a tensor of the same shape (the inter models' per-element quantisation step). */

@@ -40,7 +40,7 @@ class Ops:
         self.mask_step_dec = _f("dcvc_mask_step_dec", [vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci,
                                                        ci, ci, ci, ci, ci, vp])
         self.ffn_fused = _f("dcvc_ffn_fused", [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp])
-        self.dcb_tail = _f("dcvc_dcb_tail", [vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci,
+        self.dcb_tail = _f("dcvc_dcb_tail", [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci,
                                              ci, ci, ci, ci, ci, ci, vp])
         self.scale_clamped = _f("dcvc_scale_clamped", [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp])
 

@@ -416,15 +416,20 @@ def test_ffn_fused_equals_two_launches(ops, P, C, CF, res2, quant, q2, inplace):
         assert (ybuf[:, C:] == 9.0).all()
 
 
-@pytest.mark.parametrize("H,W,C,CD,CF,use_dw,shortcut,quant,q2", [
-    (8, 16, 256, 128, 128, True, False, False, False),
-    (13, 37, 256, 128, 128, True, True, False, False),
-    (24, 40, 128, 64, 64, True, False, True, True),
-    (17, 30, 256, 64, 192, False, False, True, False),
-    (136, 240, 256, 128, 128, True, False, False, True),
-    (136, 240, 128, 64, 64, True, True, False, False),
+@pytest.mark.parametrize("H,W,C,CD,CF,use_dw,shortcut,quant,q2,dc0", [
+    (8, 16, 256, 128, 128, True, False, False, False, False),
+    (13, 37, 256, 128, 128, True, True, False, False, False),
+    (24, 40, 128, 64, 64, True, False, True, True, False),
+    (17, 30, 256, 64, 192, False, False, True, False, False),
+    (136, 240, 256, 128, 128, True, False, False, True, False),
+    (136, 240, 128, 64, 64, True, True, False, False, False),
+    (8, 16, 256, 128, 128, True, False, False, False, True),
+    (13, 37, 256, 128, 128, True, True, False, False, True),
+    (24, 40, 128, 64, 64, True, False, True, True, True),
+    (136, 240, 256, 128, 128, True, False, False, True, True),
+    (136, 240, 128, 64, 64, True, True, False, False, True),
 ])
-def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, quant, q2):
+def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, quant, q2, dc0):
     """depthwise + dc.3 + ffn.0 + ffn.2 in one launch == dwconv3x3, conv1x1(residual),
     conv1x1(wsilu, chunk_add), conv1x1(residuals, quant) one after the other, bit for bit, on
     pictures that do and do not divide into 8x16 patches."""
@@ -445,6 +450,10 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     qq = (_rand((C,), 0.2, 111) + 1.0).half().to(dev) if q2 else None
     if shortcut and quant:
         pytest.skip("quant with two residuals is not a reference op")
+    w1 = (_rand((CD, C), 1.0, 112) / C ** 0.5).half().to(dev)
+    b1 = _rand((CD,), 0.3, 113).to(dev)
+    if dc0:         # t1 = dc.0 of the block input (five launches in total)
+        call(ops.conv1x1, ptr(xbuf), ldx, ptr(w1), ptr(b1), None, 0, None, 0, None, None, ptr(t1), CD, P, C, CD, 1, stream())
     # four launches
     t2 = torch.zeros((P, CD), dtype=torch.half, device=dev)
     if use_dw:
@@ -459,9 +468,11 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     call(ops.conv1x1, ptr(t3), CF, ptr(w2), ptr(b2), ptr(y1), C, ptr(xbuf) if shortcut else None, ldx, ptr(q), ptr(qq),
          ptr(want), C, P, CF, C, 0, stream())
     torch.cuda.synchronize()
-    # one launch, in place on the block buffer (as the codec runs it)
+    # one launch: in place on the block buffer (as the codec runs the tail), out of place with dc.0 inside
     ybuf = xbuf.clone()
-    call(ops.dcb_tail, ptr(t1), CD, ptr(dww) if use_dw else None, ptr(ybuf), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0),
+    xin = xbuf if dc0 else ybuf
+    call(ops.dcb_tail, ptr(w1) if dc0 else None, ptr(b1) if dc0 else None, None if dc0 else ptr(t1), CD,
+         ptr(dww) if use_dw else None, ptr(xin), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0),
          ptr(w2), ptr(b2), ptr(q), ptr(qq), ptr(ybuf), ldx, H, W, C, CD, CF, 1 if shortcut else 0, stream())
     torch.cuda.synchronize()
     bad = int((ybuf[:, :C] != want).sum())
