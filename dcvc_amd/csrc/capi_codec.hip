@@ -254,6 +254,20 @@ int dcvc_dmcht_decompress(dcvc_dmcht* c, const uint8_t* bit_stream, size_t nbyte
     });
 }
 
+int64_t dcvc_dmcht_export_state(dcvc_dmcht* c, void* dst, size_t cap, void* stream)
+{
+    int64_t n = -1;
+    const int rc = dcvc::guarded([&] {
+        n = static_cast<int64_t>(c->codec.export_state(dst, cap, static_cast<hipStream_t>(stream)));
+    });
+    return rc < 0 ? rc : n;
+}
+
+int dcvc_dmcht_import_state(dcvc_dmcht* c, const void* src, size_t bytes, int height, int width, void* stream)
+{
+    return dcvc::guarded([&] { c->codec.import_state(src, bytes, height, width, static_cast<hipStream_t>(stream)); });
+}
+
 int dcvc_dmcht_set_use_graphs(dcvc_dmcht* c, int on)
 {
     return dcvc::guarded([&] { c->codec.set_use_graphs(on != 0); });

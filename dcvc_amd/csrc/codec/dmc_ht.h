@@ -40,6 +40,11 @@ public:
 
     size_t debug_read(const std::string& name, void* dst, size_t cap, hipStream_t stream);
 
+    // Temporal state (reference feature, memory | feature_p, ctx + validity flags) as one flat DEVICE
+    // buffer, for moving a running GOP to another GPU (see DmcLdCodec::export_state).
+    size_t export_state(void* dst, size_t cap, hipStream_t stream);
+    void import_state(const void* src, size_t bytes, int height, int width, hipStream_t stream);
+
 private:
     struct Geometry {
         int H8 = 0, W8 = 0, H16 = 0, W16 = 0, H16p = 0, W16p = 0, H32 = 0, W32 = 0, H64 = 0, W64 = 0;

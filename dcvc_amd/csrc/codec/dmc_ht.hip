@@ -543,6 +543,70 @@ void DmcHtCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
     m_enc_ready = false;                   // ctx was advanced by this chunk; the encoder side must be re-seeded
 }
 
+// ------------------------------------------------------------------------------------ state hand-off
+namespace {
+
+struct HtStateHeader {
+    uint32_t magic, h8, w8, flags;
+    uint32_t reserved[12];
+};
+constexpr uint32_t kHtMagic = 0x44434854;     // "DCHT"
+
+}  // namespace
+
+size_t DmcHtCodec::export_state(void* dst, size_t cap, hipStream_t user)
+{
+    if (!m_has_params || m_g.H8 == 0) throw std::runtime_error("DMC-HT export_state: no state yet");
+    const Geometry& g = m_g;
+    const size_t n_fi = static_cast<size_t>(g.P8()) * kChSrcI, n_catm = static_cast<size_t>(g.P8()) * (kChM + kChD),
+                 n_ctx = static_cast<size_t>(g.P8()) * kChD;
+    const size_t bytes = sizeof(HtStateHeader) + 2 * (n_fi + n_catm + n_ctx);
+    if (dst == nullptr) return bytes;
+    if (cap < bytes) throw std::invalid_argument("export_state: destination too small");
+    hipStream_t st = enter(user);
+    HtStateHeader h{};
+    h.magic = kHtMagic ^ (m_hts ? 1u : 0u); h.h8 = g.H8; h.w8 = g.W8;
+    h.flags = (m_has_ref ? 1u : 0u) | (m_enc_ready ? 2u : 0u) | (m_memory_has_value ? 4u : 0u) | (m_has_feature_p ? 8u : 0u);
+    char* out = static_cast<char*>(dst);
+    hip_check(hipMemcpyAsync(out, &h, sizeof(h), hipMemcpyHostToDevice, st), "state header");
+    hip_check(hipStreamSynchronize(st), "sync");
+    out += sizeof(h);
+    hip_check(hipMemcpyAsync(out, m_FI, 2 * n_fi, hipMemcpyDeviceToDevice, st), "state D2D");
+    out += 2 * n_fi;
+    hip_check(hipMemcpyAsync(out, m_CATM, 2 * n_catm, hipMemcpyDeviceToDevice, st), "state D2D");
+    out += 2 * n_catm;
+    hip_check(hipMemcpy2DAsync(out, 2 * kChD, m_CATE + kChSrc, 2 * (kChSrc + kChD), 2 * kChD, g.P8(), hipMemcpyDeviceToDevice, st), "state ctx");
+    leave(user);
+    return bytes;
+}
+
+void DmcHtCodec::import_state(const void* src, size_t bytes, int height, int width, hipStream_t user)
+{
+    prepare(height, width);
+    const Geometry& g = m_g;
+    const size_t n_fi = static_cast<size_t>(g.P8()) * kChSrcI, n_catm = static_cast<size_t>(g.P8()) * (kChM + kChD),
+                 n_ctx = static_cast<size_t>(g.P8()) * kChD;
+    if (bytes != sizeof(HtStateHeader) + 2 * (n_fi + n_catm + n_ctx)) {
+        throw std::invalid_argument("import_state: size does not match this picture size");
+    }
+    hipStream_t st = enter(user);
+    HtStateHeader h{};
+    const char* in = static_cast<const char*>(src);
+    hip_check(hipMemcpyAsync(&h, in, sizeof(h), hipMemcpyDeviceToHost, st), "state header");
+    hip_check(hipStreamSynchronize(st), "sync");
+    if (h.magic != (kHtMagic ^ (m_hts ? 1u : 0u)) || h.h8 != static_cast<uint32_t>(g.H8) || h.w8 != static_cast<uint32_t>(g.W8)) {
+        throw std::invalid_argument("import_state: not a state of this model structure and picture size");
+    }
+    in += sizeof(h);
+    hip_check(hipMemcpyAsync(m_FI, in, 2 * n_fi, hipMemcpyDeviceToDevice, st), "state D2D");
+    in += 2 * n_fi;
+    hip_check(hipMemcpyAsync(m_CATM, in, 2 * n_catm, hipMemcpyDeviceToDevice, st), "state D2D");
+    in += 2 * n_catm;
+    hip_check(hipMemcpy2DAsync(m_CATE + kChSrc, 2 * (kChSrc + kChD), in, 2 * kChD, 2 * kChD, g.P8(), hipMemcpyDeviceToDevice, st), "state ctx");
+    leave(user);
+    m_has_ref = h.flags & 1u; m_enc_ready = h.flags & 2u; m_memory_has_value = h.flags & 4u; m_has_feature_p = h.flags & 8u;
+}
+
 // ------------------------------------------------------------------------------------ debug
 size_t DmcHtCodec::debug_read(const std::string& name, void* dst, size_t cap, hipStream_t st)
 {

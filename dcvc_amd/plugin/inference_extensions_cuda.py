@@ -56,6 +56,8 @@ _HT = dict(
     decompress=_lib.fn("dcvc_dmcht_decompress", _ci,
                        [_vp, _vp, ctypes.c_size_t, _ci, _ci, _ci, _ci, _ci, _vp, _vp]),
     use_graphs=_lib.fn("dcvc_dmcht_set_use_graphs", _ci, [_vp, _ci]),
+    export_state=_lib.fn("dcvc_dmcht_export_state", ctypes.c_int64, [_vp, _vp, ctypes.c_size_t, _vp]),
+    import_state=_lib.fn("dcvc_dmcht_import_state", _ci, [_vp, _vp, ctypes.c_size_t, _ci, _ci, _vp]),
     debug_read=_lib.fn("dcvc_dmcht_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
 )
 
@@ -199,24 +201,24 @@ class DMCLDProxy(_Proxy):
         return x_hat
 
 
-def _ld_export_state(self):
+def _export_state(self):
     """-> uint8 CUDA tensor holding the temporal state (send it with torch.distributed.send)."""
-    n = _lib.check(_LD["export_state"](self._h, None, 0, _stream_ptr()))
+    n = _lib.check(self._FN["export_state"](self._h, None, 0, _stream_ptr()))
     buf = torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
-    _lib.check(_LD["export_state"](self._h, ctypes.c_void_p(buf.data_ptr()), n, _stream_ptr()))
+    _lib.check(self._FN["export_state"](self._h, ctypes.c_void_p(buf.data_ptr()), n, _stream_ptr()))
     return buf
 
 
-def _ld_import_state(self, state, height, width):
+def _import_state(self, state, height, width):
     """state: uint8 CUDA tensor from export_state() of a codec with the same parameters."""
     if state.dtype != torch.uint8 or not state.is_cuda or not state.is_contiguous():
         raise ValueError("expected a contiguous uint8 CUDA tensor")
-    _lib.check(_LD["import_state"](self._h, ctypes.c_void_p(state.data_ptr()), state.numel(), int(height),
-                                   int(width), _stream_ptr()))
+    _lib.check(self._FN["import_state"](self._h, ctypes.c_void_p(state.data_ptr()), state.numel(), int(height),
+                                        int(width), _stream_ptr()))
 
 
-DMCLDProxy.export_state = _ld_export_state
-DMCLDProxy.import_state = _ld_import_state
+DMCLDProxy.export_state = _export_state
+DMCLDProxy.import_state = _import_state
 
 
 class _DMCHTProxy(_Proxy):
@@ -250,6 +252,10 @@ class _DMCHTProxy(_Proxy):
                                      1 if reset_feature_memory else 0,
                                      ctypes.c_void_p(self._x_hat.data_ptr()), _stream_ptr()))
         return [self._x_hat[i:i + 1] for i in range(self.FRAMES)]
+
+
+_DMCHTProxy.export_state = _export_state
+_DMCHTProxy.import_state = _import_state
 
 
 class DMCHTSProxy(_DMCHTProxy):

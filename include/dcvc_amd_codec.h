@@ -129,6 +129,9 @@ int64_t dcvc_dmcht_get_stream(dcvc_dmcht* c, uint8_t* dst, size_t cap);
 int dcvc_dmcht_decompress(dcvc_dmcht* c, const uint8_t* bit_stream, size_t nbytes, int qp, int height,
                           int width, int ec_parallel, int reset_feature_memory, void* x_hat,
                           void* stream);
+/* GOP hand-off between GPUs, as dcvc_dmcld_export_state / _import_state */
+int64_t dcvc_dmcht_export_state(dcvc_dmcht* c, void* dst, size_t cap, void* stream);
+int dcvc_dmcht_import_state(dcvc_dmcht* c, const void* src, size_t bytes, int height, int width, void* stream);
 int dcvc_dmcht_set_use_graphs(dcvc_dmcht* c, int on);
 /* Test hook ("y", "y_hat", "common", "z_i8", "memory", "feature_p", "ctx", "feature_i", "symbols",
  * "totals"). */

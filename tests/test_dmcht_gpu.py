@@ -144,3 +144,29 @@ def test_wrong_structure_and_missing_reference_fail_loudly():
     g = _gpu_net(m)
     with pytest.raises(Exception, match="reference feature"):
         g.compress(to_device_input(chunk(64, 64, 1)), 20, 0, 0, 0)
+
+
+def test_gop_hand_off_continues_bit_exactly():
+    """HT-S encoder / decoder state exported after a chunk and imported into fresh codec objects
+    continue with exactly the bytes / pixels of the uninterrupted codecs."""
+    m = dmc_ht_model("hts", skip_thres=0.15)
+    hw = (64, 96)
+    ref = to_device_input(_padded(picture(*hw, index=0)))
+    xs = [to_device_input(chunk(hw[0], hw[1], 1 + 8 * i)) for i in range(2)]
+    sps = {"height": hw[0], "width": hw[1]}
+    enc, dec, enc2, dec2 = _gpu_net(m), _gpu_net(m), _gpu_net(m), _gpu_net(m)
+    pb, pr = _pads(enc, *hw)
+    enc.add_ref_feature_from_frame(ref)
+    dec.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+    r0 = enc.compress(xs[0], 30, 0, pb, pr)
+    dec.decompress(r0["bit_stream"], sps, 30, r0["ec_parallel"], 0)
+    enc2._ensure_proxy().import_state(enc.proxy.export_state(), hw[0], hw[1])
+    dec2._ensure_proxy().import_state(dec.proxy.export_state(), hw[0], hw[1])
+    r1 = enc.compress(xs[1], 34, 0, pb, pr)
+    d1 = torch.cat(dec.decompress(r1["bit_stream"], sps, 34, r1["ec_parallel"], 0)["x_hat"], 0).clone()
+    r2 = enc2.compress(xs[1], 34, 0, pb, pr)
+    d2 = torch.cat(dec2.decompress(r2["bit_stream"], sps, 34, r2["ec_parallel"], 0)["x_hat"], 0)
+    torch.cuda.synchronize()
+    assert r2["bit_stream"] == r1["bit_stream"] and torch.equal(d2, d1)
+    with pytest.raises(Exception, match="model structure"):
+        _gpu_net(dmc_ht_model("htl", skip_thres=0.15))._ensure_proxy().import_state(enc.proxy.export_state(), hw[0], hw[1])
