@@ -47,6 +47,10 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--frames", type=int, default=5, help="distinct synthetic pictures per rank")
+    p.add_argument("--lanes", type=int, default=int(os.environ.get("DCVC_BENCH_LANES", "1")),
+                   help="independent coding lanes per GPU: each lane owns its codec objects, a HIP stream and a host "
+                        "thread and codes its own pictures; one step = every lane codes one unit (a batch of "
+                        "`lanes` units in flight on the GPU)")
     p.add_argument("--workload", default="intra", choices=("intra", "ld", "hts", "htl"),
                    help="intra = the headline configuration (BASELINE.json configs[1]); ld / hts / htl = the inter "
                         "models of configs[2] (one step = one call: 1 picture for ld, a chunk of 8 for hts / htl)")
@@ -242,10 +246,16 @@ def main():
     cpu_net, gpu_net = build_model(device)
     pics = make_pictures(args.frames, rank, device)
     pad_r, pad_b = gpu_net.get_padding_size(HEIGHT, WIDTH, 16)
-    if args.workload == "intra":
-        work = IntraWorkload(gpu_net, pics, pad_b, pad_r)
-    else:
-        work = InterWorkload(args.workload, device, pics, gpu_net, pad_b, pad_r)
+    def make_work(lane):
+        lane_pics = pics if lane == 0 else make_pictures(args.frames, rank + 1000 * lane, device)
+        if args.workload == "intra":
+            return IntraWorkload(gpu_net if lane == 0 else _to_gpu(cpu_net, device), lane_pics, pad_b, pad_r)
+        return InterWorkload(args.workload, device, lane_pics, gpu_net, pad_b, pad_r)
+
+    # args.lanes independent lanes per GPU (dcvc_amd/lanes.py): lane 0 is also the single-lane reference run
+    from dcvc_amd.lanes import LanePool
+    pool = LanePool(args.lanes, make_work, device)
+    work = pool.states[0]
 
     def sync():
         if dist is not None:
@@ -253,16 +263,31 @@ def main():
         torch.cuda.synchronize()
 
     if os.environ.get("DCVC_BENCH_EAGER"):          # experiment: eager launches instead of hipGraph replay
-        work.set_use_graphs(False)
-    for i in range(args.warmup):
-        work.step(i, QPS[i % len(QPS)])
+        for w in pool.states:
+            w.set_use_graphs(False)
+
+    def run_steps(first, n):
+        """every lane codes n units (lane k starts at qp offset k) -> coded bytes of all lanes."""
+        if len(pool) == 1:
+            return sum(work.step(first + i, QPS[i % len(QPS)]) for i in range(n))
+        return sum(pool.run_each(
+            lambda k, w: sum(w.step(first + i, QPS[(i + k) % len(QPS)]) for i in range(n))))
+
+    pool.warm(lambda k, w: [w.step(i, QPS[i % len(QPS)]) for i in range(args.warmup)])
     sync()
-    nbytes = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        nbytes += work.step(args.warmup + i, QPS[i % len(QPS)])
+    nbytes = run_steps(args.warmup, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    single = None
+    if len(pool) > 1 and rank == 0:             # the same workload with ONE unit in flight (latency view), untimed for `value`
+        n1 = max(5, args.steps // 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n1):
+            work.step(args.warmup + args.steps + i, QPS[i % len(QPS)])
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - t1) / n1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,7 +296,8 @@ def main():
     if rank == 0:
         names = {"intra": "DCVC-UF-Intra (DMCI)", "ld": "DCVC-UF inter LD (DMC low-delay)",
                  "hts": "DCVC-UF inter HT-S (8-picture chunks)", "htl": "DCVC-UF inter HT-L (8-picture chunks)"}
-        fps = world * args.steps * work.frames / elapsed
+        units = args.steps * args.lanes                 # units coded per rank in the timed region
+        fps = world * units * work.frames / elapsed
         out = {
             "metric": "1080p YUV420 %s encode+decode pictures per second (%s, real rANS bit streams, "
                       "q_index in {0,16,32,48,63})" % ("intra" if args.workload == "intra" else "inter", names[args.workload]),
@@ -281,12 +307,17 @@ def main():
             "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the "
                     "reference architecture)",
             "config": {"workload": "%s 1080p YUV420 on 1xMI355X per rank, q_index cycling {0,16,32,48,63}, "
-                                   "skip_thres 0.15, one step = compress + decompress of %d picture(s)"
-                                   % (names[args.workload], work.frames),
-                       "pictures_per_step": work.frames, "resolution": "%dx%d" % (WIDTH, HEIGHT)},
-            "bytes_per_picture": nbytes / args.steps / work.frames,
-            "bpp": 8.0 * nbytes / args.steps / work.frames / (HEIGHT * WIDTH),
+                                   "skip_thres 0.15, one step = compress + decompress of %d picture(s)%s"
+                                   % (names[args.workload], work.frames * args.lanes,
+                                      "" if args.lanes == 1 else " (%d independent lanes x %d in flight)" % (args.lanes, work.frames)),
+                       "pictures_per_step": work.frames * args.lanes, "lanes": args.lanes,
+                       "resolution": "%dx%d" % (WIDTH, HEIGHT)},
+            "bytes_per_picture": nbytes / units / work.frames,
+            "bpp": 8.0 * nbytes / units / work.frames / (HEIGHT * WIDTH),
         }
+        if single is not None:
+            out["one_lane"] = {"value": work.frames / single, "unit": "frames/s per GPU", "ms_per_unit": 1e3 * single,
+                               "note": "same workload, one unit in flight on the GPU (the reference's sequential loop)"}
         if not args.no_roofline:
             out["roofline"] = roofline(work)
         if not args.no_cpu_baseline and args.workload == "intra":
