@@ -11,6 +11,9 @@ One step = compress one picture to a real rANS bit stream + decompress it again
 (DMCI.compress + DMCI.decompress of the reference surface, host entropy coding included),
 pictures already resident in HBM as fp16 NHWC tensors. Every rank codes its own pictures
 (all-intra pictures are independent: no data-path collective), value = pictures/s of the job.
+--lanes L (default 1 = the reference's sequential loop) keeps L independent pictures in flight per
+GPU (dcvc_amd/lanes.py: own codec objects, stream and host thread per lane; one step = every lane
+codes one picture); the one-picture-in-flight rate is then reported beside it as "one_lane".
 
 One JSON line on rank 0 with the fields of the driver contract plus
   roofline     - conv_gemm (the matrix-core contraction kernel, >99 % of the FLOPs): algorithmic
@@ -42,15 +45,17 @@ MFMA_PEAK_TFLOPS = 2500.0        # dense fp16 MFMA, /opt/skills/guides/MI355X_MI
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=40)
-    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--steps", type=int, default=60)
+    p.add_argument("--warmup", type=int, default=15)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--frames", type=int, default=5, help="distinct synthetic pictures per rank")
-    p.add_argument("--lanes", type=int, default=int(os.environ.get("DCVC_BENCH_LANES", "1")),
+    p.add_argument("--lanes", type=int, default=int(os.environ.get("DCVC_BENCH_LANES", "0")),
                    help="independent coding lanes per GPU: each lane owns its codec objects, a HIP stream and a host "
                         "thread and codes its own pictures; one step = every lane codes one unit (a batch of "
-                        "`lanes` units in flight on the GPU)")
+                        "`lanes` units in flight on the GPU). 0 = default = 1: the reference's sequential "
+                        "loop (measured sweep in profiles/README.md: 2 lanes +5..15 %% intra, +3..5 %% LD, "
+                        "-15 %% HT over one lane)")
     p.add_argument("--workload", default="intra", choices=("intra", "ld", "hts", "htl"),
                    help="intra = the headline configuration (BASELINE.json configs[1]); ld / hts / htl = the inter "
                         "models of configs[2] (one step = one call: 1 picture for ld, a chunk of 8 for hts / htl)")
@@ -115,7 +120,8 @@ class InterWorkload:
         else:
             self.inputs = [torch.cat([pics[(i + j) % len(pics)] for j in range(8)], dim=1).contiguous(
                 memory_format=torch.channels_last) for i in range(len(pics))]
-        self.proxies = lambda: (self.enc.proxy, self.dec.proxy)
+        # launch mode of the timed region: the codec's own default (LD launches eagerly, dmc_ld.hip:24-26)
+        self.graphs = kind != "ld" and not os.environ.get("DCVC_BENCH_EAGER")
 
     def step(self, i, qp):
         if i % self.gop == 0:
@@ -138,6 +144,7 @@ class IntraWorkload:
 
     def __init__(self, gpu_net, pics, pad_b, pad_r):
         self.net, self.pics, self.pad_b, self.pad_r = gpu_net, pics, pad_b, pad_r
+        self.graphs = not os.environ.get("DCVC_BENCH_EAGER")
 
     def step(self, i, qp):
         enc, _ = step(self.net, self.pics[i % len(self.pics)], qp, self.pad_b, self.pad_r)
@@ -204,7 +211,7 @@ def roofline(work):
                 f.write("%d,%d,%d,%d,%.1f,%.2f,%.1f,%.3f\n" % (
                     k + (a[0] / n, 1e3 * a[1] / a[0], 2.0 * k[0] * k[1] * k[2] / (a[1] / a[0] * 1e-3) / 1e12, a[1] / n)))
     _lib.check(en(0))
-    work.set_use_graphs(True)
+    work.set_use_graphs(work.graphs)
     achieved = fl.value / (ms.value * 1e-3) / 1e12
     # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the
     # rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE average over the conv_gemm launches
@@ -253,9 +260,19 @@ def main():
         return InterWorkload(args.workload, device, lane_pics, gpu_net, pad_b, pad_r)
 
     # args.lanes independent lanes per GPU (dcvc_amd/lanes.py): lane 0 is also the single-lane reference run
+    import contextlib
     from dcvc_amd.lanes import LanePool
-    pool = LanePool(args.lanes, make_work, device)
+    if args.lanes == 0:
+        args.lanes = 1
+    one = args.lanes == 1 and not os.environ.get("DCVC_BENCH_POOL1")       # plain loop on the caller's stream
+    pool = LanePool(args.lanes, (lambda k: None) if one else make_work, device)
+    if one:
+        pool.states[0] = make_work(0)
     work = pool.states[0]
+    # the single-lane passes (one_lane, roofline) of a multi-lane run go through lane 0's own stream, as
+    # the lane does in the timed region (DCVC_BENCH_USER_STREAM=side|null forces either: experiments)
+    us = os.environ.get("DCVC_BENCH_USER_STREAM", "null" if args.lanes == 1 else "side")
+    lane0 = (lambda: pool._on_lane(0)) if us == "side" else contextlib.nullcontext
 
     def sync():
         if dist is not None:
@@ -269,25 +286,41 @@ def main():
     def run_steps(first, n):
         """every lane codes n units (lane k starts at qp offset k) -> coded bytes of all lanes."""
         if len(pool) == 1:
-            return sum(work.step(first + i, QPS[i % len(QPS)]) for i in range(n))
+            with lane0():
+                return sum(work.step(first + i, QPS[i % len(QPS)]) for i in range(n))
         return sum(pool.run_each(
             lambda k, w: sum(w.step(first + i, QPS[(i + k) % len(QPS)]) for i in range(n))))
 
-    pool.warm(lambda k, w: [w.step(i, QPS[i % len(QPS)]) for i in range(args.warmup)])
+    if one:
+        with lane0():
+            for i in range(args.warmup):
+                work.step(i, QPS[i % len(QPS)])
+    else:
+        pool.warm(lambda k, w: [w.step(i, QPS[i % len(QPS)]) for i in range(args.warmup)])
+    # Untimed single-lane passes on lane 0 (multi-lane runs: before the timed region, through lane 0's
+    # own stream): the one-unit-in-flight rate and the per-launch kernel times.
+    single, roof = None, None
+    if rank == 0:
+        if len(pool) > 1:
+            n1 = max(5, args.steps // 2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            with lane0():
+                for i in range(n1):
+                    work.step(args.warmup + i, QPS[i % len(QPS)])
+            torch.cuda.synchronize()
+            single = (time.perf_counter() - t1) / n1
+        if not args.no_roofline and len(pool) > 1:
+            with lane0():
+                roof = roofline(work)
     sync()
     t0 = time.perf_counter()
     nbytes = run_steps(args.warmup, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
-    single = None
-    if len(pool) > 1 and rank == 0:             # the same workload with ONE unit in flight (latency view), untimed for `value`
-        n1 = max(5, args.steps // 2)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(n1):
-            work.step(args.warmup + args.steps + i, QPS[i % len(QPS)])
-        torch.cuda.synchronize()
-        single = (time.perf_counter() - t1) / n1
+    if rank == 0 and not args.no_roofline and len(pool) == 1:
+        with lane0():
+            roof = roofline(work)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -318,8 +351,8 @@ def main():
         if single is not None:
             out["one_lane"] = {"value": work.frames / single, "unit": "frames/s per GPU", "ms_per_unit": 1e3 * single,
                                "note": "same workload, one unit in flight on the GPU (the reference's sequential loop)"}
-        if not args.no_roofline:
-            out["roofline"] = roofline(work)
+        if roof is not None:
+            out["roofline"] = roof
         if not args.no_cpu_baseline and args.workload == "intra":
             out["cpu_baseline"] = cpu_baseline(cpu_net)
         print(json.dumps(out), flush=True)

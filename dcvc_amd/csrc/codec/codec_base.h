@@ -102,6 +102,7 @@ protected:
     RansDecoder m_dec;
     hipStream_t m_io_stream = nullptr;    // D2H / H2D of symbols, high priority
     hipStream_t m_cs = nullptr;           // the codec's compute stream
+    hipStream_t m_join = nullptr;    // blocking stream that joins our results to the legacy null stream
     bool m_use_graphs = true;
 
 private:

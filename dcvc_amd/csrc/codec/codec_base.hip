@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 namespace dcvc {
 
@@ -32,6 +33,7 @@ CodecBase::~CodecBase()
     if (m_ev_job) (void)hipEventDestroy(m_ev_job);
     if (m_ev_in) (void)hipEventDestroy(m_ev_in);
     if (m_ev_out) (void)hipEventDestroy(m_ev_out);
+    if (m_join) (void)hipStreamDestroy(m_join);
     if (m_cs) (void)hipStreamDestroy(m_cs);
     if (m_io_stream) (void)hipStreamDestroy(m_io_stream);
 }
@@ -64,6 +66,26 @@ void CodecBase::bind_stage_arg(int key, const void* arg)
     slot.arg = arg;
 }
 
+namespace {
+// How results are handed to a caller that lives on the legacy NULL stream (torch's default stream,
+// i.e. the reference harness). hipStreamWaitEvent(NULL stream, event) is effectively host-blocking
+// on ROCm 7.2: measured on MI355X (tools/ramp_probe.py, LD 1080p) 167 pictures/s with it against
+// 277 with a torch side stream as the user stream - the host cannot run ahead of the GPU any more.
+// Instead a BLOCKING stream of ours carries the wait: the legacy null stream orders every later
+// operation of its own behind all blocking streams, so a consumer on it sees finished results
+// without any call on the null stream itself (266 pictures/s; a clone() queued on the null stream
+// right behind decompress, no host sync, saw the finished picture in 8 of 8 calls, and an
+// unfinished one in 8 of 8 with no join at all). DCVC_NULL_STREAM_JOIN=event restores the plain wait.
+bool join_by_blocking_stream()
+{
+    static const bool on = [] {
+        const char* e = getenv("DCVC_NULL_STREAM_JOIN");
+        return e == nullptr || std::string(e) != "event";
+    }();
+    return on;
+}
+}  // namespace
+
 hipStream_t CodecBase::enter(hipStream_t user)
 {
     hip_check(hipEventRecord(m_ev_in, user), "hipEventRecord(in)");
@@ -74,6 +96,11 @@ hipStream_t CodecBase::enter(hipStream_t user)
 void CodecBase::leave(hipStream_t user)
 {
     hip_check(hipEventRecord(m_ev_out, m_cs), "hipEventRecord(out)");
+    if (user == nullptr && join_by_blocking_stream()) {
+        if (m_join == nullptr) hip_check(hipStreamCreateWithFlags(&m_join, hipStreamDefault), "hipStreamCreate(join)");
+        hip_check(hipStreamWaitEvent(m_join, m_ev_out, 0), "hipStreamWaitEvent(join)");
+        return;
+    }
     hip_check(hipStreamWaitEvent(user, m_ev_out, 0), "hipStreamWaitEvent(out)");
 }
 

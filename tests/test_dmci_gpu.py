@@ -138,3 +138,24 @@ def test_lanes_code_the_same_bytes():
         assert r[0] == w[0], "picture %d: bytes differ" % i
         assert torch.equal(r[1], w[1]) and torch.equal(r[2], w[2]), "picture %d: reconstruction differs" % i
         assert torch.equal(r[1], r[2])
+
+
+def test_null_stream_consumer_sees_finished_results():
+    """compress() returns as soon as the bit stream is complete - the reconstruction tail is still
+    running on the codec's stream. A consumer queued on torch's default (legacy null) stream right
+    behind it, no host synchronisation, must read the finished picture (CodecBase::leave joins the
+    results through a blocking stream; tests/test_dmcld_gpu.py has the decoder-side twin)."""
+    m, g = _gpu_net(0.15)
+    hw = (720, 1280)
+    pr, pb = g.get_padding_size(hw[0], hw[1], 16)
+    assert torch.cuda.current_stream().cuda_stream == 0
+    for i in range(4):
+        x = to_device_input(picture(*hw, index=i))
+        r = g.compress(x, 20 + 10 * i, pb, pr)
+        early = r["x_hat"].clone()
+        d = g.decompress(r["bit_stream"], {"height": hw[0], "width": hw[1]}, 20 + 10 * i, r["ec_parallel"])["x_hat"]
+        seen = d.clone()
+        torch.cuda.synchronize()
+        assert torch.equal(early, r["x_hat"]), "picture %d: unfinished encoder-side reconstruction" % i
+        assert torch.equal(seen, d), "picture %d: unfinished decoder-side reconstruction" % i
+        assert torch.equal(early, seen)

@@ -203,3 +203,26 @@ def test_gop_hand_off_continues_bit_exactly():
         assert torch.equal(d, want[i][1])
     with pytest.raises(Exception, match="picture size"):
         enc2.proxy.import_state(s_enc, 64, 64)
+
+
+def test_null_stream_consumer_sees_finished_results():
+    """The caller of the reference harness lives on torch's default (= legacy null) stream. Results
+    are joined to it through a blocking stream instead of hipStreamWaitEvent(null stream)
+    (codec_base.hip, CodecBase::leave): a consumer queued on the null stream right behind
+    decompress - no host synchronisation in between - must read the finished picture."""
+    m = dmc_ld_model(skip_thres=0.15)
+    hw = (720, 1280)
+    ref = to_device_input(_padded(picture(*hw, index=0)))
+    enc, dec = _gpu_net(m), _gpu_net(m)
+    pb, pr = _pads(enc, *hw)
+    enc.add_ref_feature_from_frame(ref)
+    dec.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+    sps = {"height": hw[0], "width": hw[1]}
+    assert torch.cuda.current_stream().cuda_stream == 0
+    for i in range(6):
+        x = to_device_input(picture(*hw, index=1 + i))
+        r = enc.compress(x, 30 + i, 0, pb, pr)
+        d = dec.decompress(r["bit_stream"], sps, 30 + i, r["ec_parallel"], 0)["x_hat"]
+        seen = d.clone()                           # queued on the null stream, no host sync
+        torch.cuda.synchronize()
+        assert torch.equal(seen, d), "picture %d: the consumer read an unfinished reconstruction" % i
