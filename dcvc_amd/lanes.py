@@ -3,14 +3,18 @@
 The reference codes one picture at a time on one stream (test_video.py:186-366); a picture's
 decode has four GPU -> CPU -> GPU round trips (dmci_proxy.cpp:857-871: each masked group needs the
 entropy decoder's symbols before the next prior can be computed) and every kernel boundary drains
-the chip, so a single sequence cannot fill 256 CUs: measured on MI355X at 1080p, a second lane adds
-+15 % (intra) to +69 % (LD) pictures/s (profiles/README.md). Pictures of an all-intra sequence, GOPs
-of an inter sequence and the qps of a rate sweep are independent units (the same units
-`dcvc_amd.sharding` deals over GPUs), so one process per GPU keeps `n` of them in flight:
+the chip. Pictures of an all-intra sequence, GOPs of an inter sequence and the qps of a rate sweep
+are independent units (the same units `dcvc_amd.sharding` deals over GPUs), so one process per GPU
+can keep `n` of them in flight:
 
   lane = its own codec objects (own resident buffers, compute stream, entropy-coding worker - the
          objects `factory(lane_index)` returns), one torch side stream for the tensors that cross
          the plugin boundary, one host thread issuing the reference-surface calls.
+
+Measured on MI355X at 1080p (profiles/README.md, v5), two lanes against one lane: intra +5..15 %,
+LD +3..5 %, HT-S / HT-L -15 %; more than two lanes lose everywhere - the contraction kernel owns a
+whole CU, lanes only fill boundary and round-trip gaps and share L2 / MALL. Use it to serve several
+streams from one GPU, not as a throughput trick; bench.py runs one lane.
 
 Nothing is shared between lanes and every unit runs through exactly the single-lane path, so the
 bytes and reconstructions of a unit do not depend on the number of lanes
