@@ -1,5 +1,6 @@
 // C ABI of the individual kernels (include/dcvc_amd_ops.h).
 #include "capi_common.h"
+#include <mutex>
 #include "dcvc_amd_ops.h"
 #include "kernels/ops.h"
 
@@ -15,10 +16,11 @@ inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 const half_t* zero_page()
 {
     static half_t* z = nullptr;
-    if (!z) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         dcvc::hip_check(hipMalloc(&z, 4096), "hipMalloc(zero page)");
         dcvc::hip_check(hipMemset(z, 0, 4096), "hipMemset(zero page)");
-    }
+    });
     return z;
 }
 

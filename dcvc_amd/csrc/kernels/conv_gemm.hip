@@ -502,6 +502,7 @@ struct GemmProfile {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<GemmLaunchInfo> info;
     size_t used = 0;
+    std::mutex mu;          // launches may come from several host threads (lanes)
 };
 
 GemmProfile& profile()
@@ -517,16 +518,16 @@ void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHREADS = WM * WN * 64;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     auto kern = conv_gemm_kernel<WM, WN, MT, NT, STAGES, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE, XDIRECT>;
-    static bool attr_set = false;
+    static std::once_flag attr_once;      // lanes launch from several host threads
     const int smem_bytes = STAGES * ((XDIRECT ? 0 : BM) + BN) * BK * 2 + (ACT == ACT_WSILU ? WSILU_TABLE_BYTES : 0);
-    if (!attr_set) {
+    std::call_once(attr_once, [&] {
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
                   "hipFuncSetAttribute(conv_gemm)");
-        attr_set = true;
-    }
+    });
     GemmProfile& pf = profile();
     if (pf.on) {
+        std::lock_guard<std::mutex> lk(pf.mu);
         if (pf.used == pf.events.size()) {
             hipEvent_t a, b;
             hip_check(hipEventCreate(&a), "hipEventCreate");

@@ -21,6 +21,7 @@
 // Every fp16 rounding point and every contraction order is that of the four-launch path, so the
 // result is bit-identical to it (tests/test_kernels_gpu.py::test_dcb_tail_equals_four_launches).
 #include "arith.h"
+#include <mutex>
 #include "ops.h"
 #include "wsilu_table.h"
 
@@ -550,14 +551,13 @@ template <int NT2, bool DW, bool QUANT, bool DC0>
 void launch(const TailParams& p, hipStream_t stream)
 {
     auto kern = dcb_tail_kernel<NT2, DW, QUANT, DC0>;
-    static bool attr_set = false;
+    static std::once_flag attr_once;      // lanes launch from several host threads
     constexpr int C = NT2 * 128;
     constexpr int smem_bytes = (C / 64) * SLAB_BYTES + ST_BYTES + TABLE_BYTES;
-    if (!attr_set) {
+    std::call_once(attr_once, [&] {
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
                   "hipFuncSetAttribute(dcb_tail)");
-        attr_set = true;
-    }
+    });
     const int grid = ((p.H + PH - 1) / PH) * ((p.W + PW - 1) / PW);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem_bytes, stream, p);
     hip_check(hipGetLastError(), "dcb_tail launch");

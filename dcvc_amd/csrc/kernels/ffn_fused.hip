@@ -25,6 +25,7 @@
 // stages of (y1 slab 128x64 + W0 slab 256x64) = 96 KB + the 4 KB WSiLU table; between two channel
 // tiles the dead stage area holds T (16 KB), the W2 slab [C][64] and the replicated WSiLU table.
 #include "arith.h"
+#include <mutex>
 #include "ops.h"
 #include "wsilu_table.h"
 
@@ -337,13 +338,12 @@ template <int NT2, bool RES2, bool QUANT>
 void launch(const FfnParams& p, hipStream_t stream)
 {
     auto kern = ffn_fused_kernel<NT2, RES2, QUANT>;
-    static bool attr_set = false;
+    static std::once_flag attr_once;      // lanes launch from several host threads
     constexpr int smem_bytes = AREA + TABLE_BYTES;
-    if (!attr_set) {
+    std::call_once(attr_once, [&] {
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes),
                   "hipFuncSetAttribute(ffn_fused)");
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(kern, dim3((p.M + BM - 1) / BM), dim3(NTHREADS), smem_bytes, stream, p);
     hip_check(hipGetLastError(), "ffn_fused launch");
 }
