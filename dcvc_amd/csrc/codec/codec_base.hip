@@ -67,8 +67,8 @@ void CodecBase::bind_stage_arg(int key, const void* arg)
 }
 
 namespace {
-// How results are handed to a caller that lives on the legacy NULL stream (torch's default stream,
-// i.e. the reference harness). hipStreamWaitEvent(NULL stream, event) is effectively host-blocking
+// How results are handed to a caller that lives on the legacy NULL stream (torch's default stream;
+// the reference harness installs a non-default one, test_video.py:423-425, plain torch code does not). hipStreamWaitEvent(NULL stream, event) is effectively host-blocking
 // on ROCm 7.2: measured on MI355X (tools/ramp_probe.py, LD 1080p) 167 pictures/s with it against
 // 277 with a torch side stream as the user stream - the host cannot run ahead of the GPU any more.
 // Instead a BLOCKING stream of ours carries the wait: the legacy null stream orders every later

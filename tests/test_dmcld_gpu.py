@@ -206,7 +206,8 @@ def test_gop_hand_off_continues_bit_exactly():
 
 
 def test_null_stream_consumer_sees_finished_results():
-    """The caller of the reference harness lives on torch's default (= legacy null) stream. Results
+    """A caller on torch's default (= legacy null) stream - plain torch code; the reference harness
+    installs a non-default one, test_video.py:423-425. Results
     are joined to it through a blocking stream instead of hipStreamWaitEvent(null stream)
     (codec_base.hip, CodecBase::leave): a consumer queued on the null stream right behind
     decompress - no host synchronisation in between - must read the finished picture."""
