@@ -121,7 +121,7 @@ class InterWorkload:
             self.inputs = [torch.cat([pics[(i + j) % len(pics)] for j in range(8)], dim=1).contiguous(
                 memory_format=torch.channels_last) for i in range(len(pics))]
         # launch mode of the timed region: the codec's own default (LD launches eagerly, dmc_ld.hip:24-26)
-        self.graphs = kind != "ld" and not os.environ.get("DCVC_BENCH_EAGER")
+        self.graphs = (kind != "ld" or bool(os.environ.get("DCVC_BENCH_GRAPHS"))) and not os.environ.get("DCVC_BENCH_EAGER")
 
     def step(self, i, qp):
         if i % self.gop == 0:
@@ -283,9 +283,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if os.environ.get("DCVC_BENCH_EAGER"):          # experiment: eager launches instead of hipGraph replay
-        for w in pool.states:
-            w.set_use_graphs(False)
+    if os.environ.get("DCVC_BENCH_EAGER") or os.environ.get("DCVC_BENCH_GRAPHS"):
+        for w in pool.states:      # experiments: force eager launches / hipGraph replay (LD launches eagerly by default)
+            w.set_use_graphs(w.graphs)
 
     def run_steps(first, n):
         """every lane codes n units (lane k starts at qp offset k) -> coded bytes of all lanes."""
