@@ -22,7 +22,11 @@ ARCH = "gfx950"
 # libdcvc_amd_<name>.so with the extra defines below; select it at run time with DCVC_LIB=<path>
 # (dcvc_amd/_lib.py). None is defined at the moment.
 VARIANT = os.environ.get("DCVC_BUILD_VARIANT", "")
-VARIANT_DEFS = {"": []}[VARIANT]
+VARIANT_DEFS = {"": [], "pipe": ["-DDCVC_WITH_GEMM_PIPE"]}[VARIANT]
+# sources that belong to ONE build variant only (experiments that are not part of the product library):
+#   DCVC_BUILD_VARIANT=pipe python -m dcvc_amd.build  ->  libdcvc_amd_pipe.so (load it with DCVC_LIB=...)
+#   adds kernels/gemm_pipe.hip (software-pipelined ffn.0; ~17 min of hipcc) behind DCVC_GEMM_PIPE=1
+VARIANT_ONLY = {"gemm_pipe.hip": "pipe"}
 OBJ = os.path.join(CSRC, "_obj" + ("_" + VARIANT if VARIANT else ""))
 LIB = os.path.join(PKG, "libdcvc_amd%s.so" % ("_" + VARIANT if VARIANT else ""))
 
@@ -42,7 +46,8 @@ def _sources():
     srcs = []
     for pat in ("*.cpp", "*.hip", "*/*.cpp", "*/*.hip"):
         srcs += glob.glob(os.path.join(CSRC, pat))
-    return sorted(s for s in srcs if os.sep + "_obj" not in s)
+    return sorted(s for s in srcs if os.sep + "_obj" not in s
+                  and VARIANT_ONLY.get(os.path.basename(s), VARIANT) == VARIANT)
 
 
 def _headers():

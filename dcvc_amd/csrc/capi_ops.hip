@@ -317,4 +317,20 @@ long long dcvc_gemm_profile_launches(void* records, long long cap)
     return n;
 }
 
+#ifdef DCVC_WITH_GEMM_PIPE
+/* build variant "pipe" only; not part of include/dcvc_amd_ops.h. Same arguments as dcvc_conv1x1 with
+   wsilu = chunk_add = 1 and no residual / scale. */
+int dcvc_conv1x1_wsilu_chunk_pipe(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy,
+                                  int pixels, int cin, int cout, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::Conv1x1Desc d;
+        d.x = H(x); d.ldx = ldx; d.w = H(w); d.bias = H(bias); d.y = H(y); d.ldy = ldy;
+        d.pixels = pixels; d.cin = cin; d.cout = cout; d.wsilu = true; d.chunk_add = true;
+        dcvc::kernels_init();
+        dcvc::conv1x1_wsilu_chunk_pipe(d, S(stream));
+    });
+}
+#endif
+
 }  // extern "C"

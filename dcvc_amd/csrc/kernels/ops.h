@@ -56,6 +56,12 @@ struct Conv1x1Desc {
 };
 void conv1x1(const Conv1x1Desc& d, hipStream_t stream);
 
+// EXPERIMENT (build variant "pipe", gemm_pipe.hip): conv1x1 + bias + WSiLU + chunk-add with the epilogue
+// of one channel tile running inside the main loop of the next; bit-identical to conv1x1().
+bool gemm_pipe_enabled();                                       // DCVC_GEMM_PIPE=1
+bool gemm_pipe_supported(int pixels, int cin, int cout);
+void conv1x1_wsilu_chunk_pipe(const Conv1x1Desc& d, hipStream_t stream);
+
 struct ConvKxKDesc {
     const half_t* x = nullptr; int ldx = 0;     // [in_h][in_w][ldx]
     const half_t* w = nullptr;                  // [cout][ky][kx][cin]  (tap major, cin contiguous)

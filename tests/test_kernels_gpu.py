@@ -478,3 +478,38 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     bad = int((ybuf[:, :C] != want).sum())
     assert bad == 0, "%d of %d outputs differ" % (bad, want.numel())
     assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
+
+
+@pytest.mark.parametrize("P,C,N,ldx_extra", [
+    (128 * 3, 384, 256, 0),          # one channel tile: prologue + tail only
+    (128 * 2 + 5, 384, 512, 64),     # two tiles, ragged last pixel tile, x a channel slice
+    (1000, 384, 1536, 0),            # the intra ffn.0 shape (6 tiles: both accumulator sets, steady state)
+    (777, 512, 2048, 0),             # K = 512 (HT full-width ffn.0), 8 tiles
+    (32640, 384, 1536, 0),           # 1080p
+])
+def test_gemm_pipe_equals_conv_gemm(ops, P, C, N, ldx_extra):
+    """EXPERIMENT, build variant "pipe" only (DCVC_BUILD_VARIANT=pipe python -m dcvc_amd.build, then
+    DCVC_LIB=dcvc_amd/libdcvc_amd_pipe.so): the software-pipelined ffn.0 kernel (gemm_pipe.hip) gives
+    conv1x1(wsilu, chunk_add)'s output bit for bit. Skipped with the product library."""
+    import ctypes
+    from dcvc_amd import _lib
+    from gpu_util import call, ptr, stream
+    try:
+        pipe = _lib.fn("dcvc_conv1x1_wsilu_chunk_pipe", ctypes.c_int,
+                       [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
+    except AttributeError:
+        pytest.skip("the loaded library is not the 'pipe' build variant")
+    dev = "cuda"
+    ld = C + ldx_extra
+    x = _rand((P, ld), 1.0, 201).to(dev)
+    w = (_rand((N, C), 1.0, 202) / C ** 0.5).half().to(dev)
+    b = _rand((N,), 0.3, 203).to(dev)
+    want = torch.zeros((P, N // 4), dtype=torch.half, device=dev)
+    got = torch.full((P, N // 4 + 8), 9.0, dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(x), ld, ptr(w), ptr(b), None, 0, None, 0, None, None, ptr(want), N // 4, P, C, N, 3, stream())
+    call(pipe, ptr(x), ld, ptr(w), ptr(b), ptr(got), N // 4 + 8, P, C, N, stream())
+    torch.cuda.synchronize()
+    bad = int((got[:, :N // 4] != want).sum())
+    assert bad == 0, "%d of %d outputs differ" % (bad, want.numel())
+    assert (got[:, N // 4:] == 9.0).all()
