@@ -124,8 +124,8 @@ gemm_pipe_kernel(const PipeParams p)
     {
         float4* rep = reinterpret_cast<float4*>(smem + OFF_TABLE);
         for (int i = tid; i < R * WSILU_SEGMENTS; i += NTHREADS) rep[i] = p.wsilu[i / R];
-        half8* bl = reinterpret_cast<half8*>(smem + OFF_BIAS);
-        for (int i = tid; i < p.N / 8; i += NTHREADS) bl[i] = *reinterpret_cast<const half8*>(p.bias + 8 * i);
+        half4* bl = reinterpret_cast<half4*>(smem + OFF_BIAS);      // 8-B loads: conv_gemm.hip's alignment contract
+        for (int i = tid; i < p.N / 4; i += NTHREADS) bl[i] = *reinterpret_cast<const half4*>(p.bias + 4 * i);
     }
     const float4* tab = reinterpret_cast<const float4*>(smem + OFF_TABLE) + (lane & (R - 1));
     char* otile = smem + OFF_OTILE;
