@@ -357,7 +357,7 @@ def main():
                                "note": "same workload, one unit in flight on the GPU (the reference's sequential loop)"}
         if roof is not None:
             out["roofline"] = roof
-        if not args.no_cpu_baseline and args.workload == "intra":
+        if not args.no_cpu_baseline and args.workload == "intra" and world == 1:      # N = 1 only (contract)
             out["cpu_baseline"] = cpu_baseline(cpu_net)
         print(json.dumps(out), flush=True)
     if dist is not None:
