@@ -69,6 +69,30 @@ template <> constexpr int piece_at<8>(int q) { return q % 2 == 0 ? q / 2 : -1; }
 template <> constexpr int combine_at<8>(int q) { return q % 8 == 7 ? q / 8 : -1; }
 template <> constexpr bool store_at<8>(int q) { return q == 1; }
 
+// every piece exactly once and in order, a unit's combine after its four pieces, the store before the
+// first combine and behind the k-step barrier that follows the previous tile's last combine
+template <int NK> constexpr bool schedule_ok()
+{
+    int next_piece = 0, next_unit = 0;
+    bool stored = false;
+    for (int q = 0; q < 4 * NK; ++q) {
+        if (piece_at<NK>(q) >= 0) {
+            if (piece_at<NK>(q) != next_piece || combine_at<NK>(q) >= 0) return false;
+            ++next_piece;
+        }
+        if (combine_at<NK>(q) >= 0) {
+            if (combine_at<NK>(q) != next_unit || next_piece != 4 * (next_unit + 1) || !stored || q < 4) return false;
+            ++next_unit;
+        }
+        if (store_at<NK>(q)) {
+            if (stored || next_unit != 0 || q >= 4) return false;
+            stored = true;
+        }
+    }
+    return next_piece == 16 && next_unit == 4 && stored;
+}
+static_assert(schedule_ok<6>() && schedule_ok<8>(), "epilogue schedule");
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
 {
