@@ -198,6 +198,68 @@ def test_mfma_model_matches_hardware_measurements(golden_dir):
     assert bad == 0, "%d of %d trials differ" % (bad, len(c))
 
 
+def _vec_lib():
+    import ctypes
+    from oracle import nn
+    lib = nn._lib()
+    lib.orc_avx512.restype = ctypes.c_int
+    lib.orc_avx512.argtypes = [ctypes.c_int]
+    lib.orc_mfma16_vec.restype = ctypes.c_float
+    lib.orc_mfma16_vec.argtypes = [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def test_vector_contraction_matches_hardware_measurements(golden_dir):
+    """The AVX-512 restatement of the contraction arithmetic (what the oracle runs on hosts that
+    have it) against the same MI355X probe data, and against the scalar routine."""
+    import ctypes
+    lib = _vec_lib()
+    if not lib.orc_avx512(-1):
+        pytest.skip("host without AVX-512: the oracle runs the scalar routine")
+    d = np.load(os.path.join(golden_dir, "mfma_probe.npz"))
+    a, b, c, out = d["a"], d["b"], d["c"], d["d"]
+    bad = 0
+    for i in range(len(c)):
+        ai, bi = np.ascontiguousarray(a[i]), np.ascontiguousarray(b[i])
+        w = np.float32(lib.orc_mfma16_vec(ctypes.c_float(float(c[i])), ai.ctypes.data, bi.ctypes.data))
+        if w.tobytes() != out[i].tobytes() and not (w == 0 and out[i] == 0):
+            bad += 1
+    assert bad == 0, "%d of %d trials differ" % (bad, len(c))
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide", "sparse", "bits"])
+def test_vector_and_scalar_contractions_are_identical(kind):
+    from oracle import nn
+    lib = _vec_lib()
+    if not lib.orc_avx512(-1):
+        pytest.skip("host without AVX-512")
+    rng = np.random.default_rng(7)
+
+    def draw(shape):
+        if kind == "normal":
+            return (rng.standard_normal(shape) * 0.2).astype(np.float16)
+        if kind == "wide":       # exponents spread over the whole fp16 range incl. subnormals
+            return (rng.standard_normal(shape) * np.exp2(rng.integers(-24, 4, size=shape))).astype(np.float16)
+        if kind == "sparse":
+            x = rng.standard_normal(shape).astype(np.float16)
+            x[rng.random(shape) < 0.6] = 0
+            return x
+        bits = rng.integers(0, 0x7C00, size=shape).astype(np.uint16) | (rng.integers(0, 2, size=shape).astype(np.uint16) << 15)
+        return bits.view(np.float16)     # every finite bit pattern (outputs may overflow: compared as bits)
+
+    try:
+        for P, K, N, wsilu, chunk in ((37, 64, 64, False, False), (19, 128, 256, True, True), (9, 384, 64, True, False)):
+            x, w, b, r = draw((P, K)), draw((N, K)), draw((N,)), draw((P, N))
+            res = None if chunk else r
+            lib.orc_avx512(0)
+            y0 = nn.conv1x1(x, w, b, r1=res, wsilu=wsilu, chunk_add=chunk)
+            lib.orc_avx512(1)
+            y1 = nn.conv1x1(x, w, b, r1=res, wsilu=wsilu, chunk_add=chunk)
+            assert np.array_equal(y0.view(np.uint16), y1.view(np.uint16))
+    finally:
+        lib.orc_avx512(1)
+
+
 def test_c_abi_exports_every_declared_symbol():
     from tools import check_abi
     assert len(check_abi.declared_symbols()) >= 40
