@@ -18,17 +18,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 ARCH = "gfx950"
-# experiment variants live beside the product library: DCVC_BUILD_VARIANT=<name> builds
-# libdcvc_amd_<name>.so with the extra defines below; select it at run time with DCVC_LIB=<path>
-# (dcvc_amd/_lib.py). None is defined at the moment.
-VARIANT = os.environ.get("DCVC_BUILD_VARIANT", "")
-VARIANT_DEFS = {"": [], "pipe": ["-DDCVC_WITH_GEMM_PIPE"]}[VARIANT]
-# sources that belong to ONE build variant only (experiments that are not part of the product library):
-#   DCVC_BUILD_VARIANT=pipe python -m dcvc_amd.build  ->  libdcvc_amd_pipe.so (load it with DCVC_LIB=...)
-#   adds kernels/gemm_pipe.hip (software-pipelined ffn.0; ~17 min of hipcc) behind DCVC_GEMM_PIPE=1
-VARIANT_ONLY = {"gemm_pipe.hip": "pipe"}
-OBJ = os.path.join(CSRC, "_obj" + ("_" + VARIANT if VARIANT else ""))
-LIB = os.path.join(PKG, "libdcvc_amd%s.so" % ("_" + VARIANT if VARIANT else ""))
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(PKG, "libdcvc_amd.so")
 
 COMMON = [
     "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
@@ -38,7 +29,7 @@ COMMON = [
     # SLP packing of scalar fp32 math into v_pk_* costs more v_mov / s_nop than it saves on gfx950
     "-fno-slp-vectorize",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-] + VARIANT_DEFS
+]
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-munsafe-fp-atomics"]
 
 
@@ -46,8 +37,7 @@ def _sources():
     srcs = []
     for pat in ("*.cpp", "*.hip", "*/*.cpp", "*/*.hip"):
         srcs += glob.glob(os.path.join(CSRC, pat))
-    return sorted(s for s in srcs if os.sep + "_obj" not in s
-                  and VARIANT_ONLY.get(os.path.basename(s), VARIANT) == VARIANT)
+    return sorted(s for s in srcs if os.sep + "_obj" not in s)
 
 
 def _headers():

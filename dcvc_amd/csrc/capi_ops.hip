@@ -122,6 +122,22 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
     });
 }
 
+int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
+                  const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                  const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
+                  int pixels, int c, int shortcut, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::kernels_init();
+        dcvc::DcbCoreDesc d;
+        d.t2 = H(t2); d.ldt = ldt; d.x = H(x); d.ldx = ldx; d.w3 = H(w3); d.b3 = H(b3);
+        d.w0 = H(w0); d.b0 = H(b0); d.w2 = H(w2); d.b2 = H(b2); d.q = H(q); d.q2 = H(q2);
+        d.w1n = H(w1n); d.b1n = H(b1n); d.t1n = H(t1n); d.ldt1 = ldt1; d.y = H(y); d.ldy = ldy;
+        d.pixels = pixels; d.c = c; d.shortcut = shortcut != 0;
+        dcvc::dcb_core(d, S(stream));
+    });
+}
+
 int dcvc_dcb_tail(const void* w1, const void* b1, const void* t, int ldt, const void* dw, const void* x, int ldx,
                   const void* w3, const void* b3,
                   const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
@@ -317,20 +333,5 @@ long long dcvc_gemm_profile_launches(void* records, long long cap)
     return n;
 }
 
-#ifdef DCVC_WITH_GEMM_PIPE
-/* build variant "pipe" only; not part of include/dcvc_amd_ops.h. Same arguments as dcvc_conv1x1 with
-   wsilu = chunk_add = 1 and no residual / scale. */
-int dcvc_conv1x1_wsilu_chunk_pipe(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy,
-                                  int pixels, int cin, int cout, void* stream)
-{
-    return dcvc::guarded([&] {
-        dcvc::Conv1x1Desc d;
-        d.x = H(x); d.ldx = ldx; d.w = H(w); d.bias = H(bias); d.y = H(y); d.ldy = ldy;
-        d.pixels = pixels; d.cin = cin; d.cout = cout; d.wsilu = true; d.chunk_add = true;
-        dcvc::kernels_init();
-        dcvc::conv1x1_wsilu_chunk_pipe(d, S(stream));
-    });
-}
-#endif
 
 }  // extern "C"

@@ -109,7 +109,10 @@ void CodecBase::submit(hipStream_t st, std::function<void()> job)
     hip_check(hipEventRecord(m_ev_job, st), "hipEventRecord(job)");
     hip_check(hipStreamWaitEvent(m_io_stream, m_ev_job, 0), "hipStreamWaitEvent(job)");
     {
-        std::lock_guard<std::mutex> lk(m_mu);
+        // a call that threw between submit() and wait_job() leaves its job running: never hand the
+        // worker a second job (or reset its result) before the first has finished
+        std::unique_lock<std::mutex> lk(m_mu);
+        m_cv_done.wait(lk, [&] { return m_done && !m_pending; });
         m_job = std::move(job);
         m_pending = true;
         m_done = false;

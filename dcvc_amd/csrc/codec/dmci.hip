@@ -25,6 +25,7 @@ DmciCodec::~DmciCodec()
 // ------------------------------------------------------------------------------------ set_param
 void DmciCodec::set_param(const ParamStore& ps, float skip_thres)
 {
+    quiesce();            // compress() returns before its reconstruction graph has finished
     clear_graphs();
     m_wmem.release();
     kernels_init();
@@ -69,6 +70,7 @@ void DmciCodec::prepare(int height, int width)
 {
     if (!m_has_params) throw std::runtime_error("DMCI: set_param() has not been called");
     if (m_g.H == height && m_g.W == width) return;
+    quiesce();
     clear_graphs();
     m_bmem.release();
     Geometry g;
@@ -125,10 +127,16 @@ void DmciCodec::run_encoder(hipStream_t st)
     const Geometry& g = m_g;
     // dmci_proxy.cpp:92-105 (the per-channel q_scale_enc multiply is applied to the rounded
     // output of enc_1 inside its last conv's epilogue)
+    // consecutive full-width blocks hand dc.0 over: block i's launch also computes dc.0 of block i+1
+    bool handed = m_enc1.feeds(m_enc2[0]);
     m_enc1.forward(View(m_U, kChSrc, kChSrc), View(m_F, kChEncDec, kChEncDec), g.H8, g.W8, m_s, st,
-                   false, nullptr, m_cur_q_enc);
+                   false, nullptr, m_cur_q_enc, View(), handed ? &m_enc2[0] : nullptr);
     const View f(m_F, kChEncDec, kChEncDec);
-    for (int i = 0; i < 6; ++i) m_enc2[i].forward(f, f, g.H8, g.W8, m_s, st);
+    for (int i = 0; i < 6; ++i) {
+        const DcbW* next = (i < 5 && m_enc2[i].feeds(m_enc2[i + 1])) ? &m_enc2[i + 1] : nullptr;
+        m_enc2[i].forward(f, f, g.H8, g.W8, m_s, st, false, nullptr, nullptr, View(), next, handed);
+        handed = next != nullptr;
+    }
     ConvKxKDesc d;
     d.x = m_F; d.ldx = kChEncDec; d.w = m_enc_down.w; d.bias = m_enc_down.b; d.zeros = m_zeros;
     d.y = m_Y; d.ldy = kChY; d.in_h = g.H8; d.in_w = g.W8; d.cin = kChEncDec; d.cout = kChY;
@@ -194,11 +202,16 @@ void DmciCodec::run_decoder(half_t* x_hat, hipStream_t st)
 {
     const Geometry& g = m_g;
     // dmci_proxy.cpp:14-33
+    bool handed = m_dec_up.block.feeds(m_dec1[0]);
     m_dec_up.forward(View(m_YHAT, kChY, kChY), View(m_D0, kChEncDec, kChEncDec), View(m_D1, kChEncDec, kChEncDec),
-                     g.H16, g.W16, m_s, st);
+                     g.H16, g.W16, m_s, st, nullptr, nullptr, handed ? &m_dec1[0] : nullptr);
     const View d1(m_D1, kChEncDec, kChEncDec);
-    for (int i = 0; i < 11; ++i) m_dec1[i].forward(d1, d1, g.H8, g.W8, m_s, st);
-    m_dec1[11].forward(d1, d1, g.H8, g.W8, m_s, st, false, nullptr, m_cur_q_dec);
+    for (int i = 0; i < 12; ++i) {
+        const DcbW* next = (i < 11 && m_dec1[i].feeds(m_dec1[i + 1])) ? &m_dec1[i + 1] : nullptr;
+        m_dec1[i].forward(d1, d1, g.H8, g.W8, m_s, st, false, nullptr, i == 11 ? m_cur_q_dec : nullptr, View(),
+                          next, handed);
+        handed = next != nullptr;
+    }
     m_dec2.forward(d1, View(m_R, kChSrc, kChSrc), g.H8, g.W8, m_s, st);
     shuffle8(m_R, kChSrc, g.H8, g.W8, 3, true, x_hat, st);
 }

@@ -95,8 +95,15 @@ struct DcbW {
     // [pixels][c] buffer for the adaptor output; with it (or without an adaptor) and y != x the
     // half-width blocks of the inter models run as ONE launch (kernels/dcb_tail.hip reads the block
     // input of neighbouring patches, so it cannot run in place)
+    // Full-width blocks (c = 384) run everything behind the depthwise conv in one launch
+    // (kernels/dcb_core.hip), which can also compute dc.0 of the block that FOLLOWS in a chain:
+    // `next` = that block (must satisfy feeds(next)), its dc.0 output then waits in s.t1 and the
+    // caller passes dc0_done = true to next->forward().
     void forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut = false,
-                 const half_t* q_fused = nullptr, const half_t* q_after = nullptr, View alt = View()) const;
+                 const half_t* q_fused = nullptr, const half_t* q_after = nullptr, View alt = View(),
+                 const DcbW* next = nullptr, bool dc0_done = false) const;
+    bool core_fused() const;                     // this block runs through dcb_core
+    bool feeds(const DcbW& next) const;          // ... and can compute next's dc.0 on the way out
 };
 
 // layers.py:176-188: pixel_unshuffle(2) + 1x1 == 2x2 stride-2 conv (layers_proxy.cpp:263-264)
@@ -135,7 +142,7 @@ struct UpsampleW {
     // x: [H][W][cin] -> tmp, y: [2H][2W][cout]; without the shortcut tmp may be y.
     // up_tmp / zeros: only for a biased upsampler (SubpelW::tmp_elems)
     void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
-                 half_t* up_tmp = nullptr, const half_t* zeros = nullptr) const;
+                 half_t* up_tmp = nullptr, const half_t* zeros = nullptr, const DcbW* next = nullptr) const;
 };
 
 // nn.Sequential of DepthConvBlocks prefix + "0.", "1.", ... (as many as the checkpoint has)

@@ -54,7 +54,10 @@ void* DeviceArena::alloc(size_t bytes)
     void* p = nullptr;
     const size_t sz = (bytes + 255) / 256 * 256 + 256;
     hip_check(hipMalloc(&p, sz), "hipMalloc");
+    // the codec streams are non-blocking: they do not order themselves behind the null stream
+    // the fill runs on, so the fill has to be finished before the buffer is handed out
     hip_check(hipMemset(p, 0, sz), "hipMemset");
+    hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(fill)");
     m_ptrs.push_back(p);
     m_total += sz;
     return p;
@@ -158,10 +161,23 @@ void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
     }
 }
 
+bool DcbW::core_fused() const
+{
+    return dcb_core_supported(c, cdc, cffn) && dc0.b && dc3.b && ffn0.b && ffn2.b;
+}
+
+bool DcbW::feeds(const DcbW& next) const
+{
+    return core_fused() && next.core_fused() && !next.has_adaptor;
+}
+
 void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut,
-                   const half_t* q_fused, const half_t* q_after, View alt) const
+                   const half_t* q_fused, const half_t* q_after, View alt, const DcbW* next, bool dc0_done) const
 {
     const int P = H * W;
+    if ((next != nullptr && !feeds(*next)) || (dc0_done && (!core_fused() || has_adaptor))) {
+        throw std::invalid_argument("DepthConvBlock: dc.0 hand-over between blocks that do not support it");
+    }
     if (static_cast<size_t>(P) * cdc > s.elems || static_cast<size_t>(P) * cffn > s.elems) {
         throw std::runtime_error("DepthConvBlock: scratch planes too small");
     }
@@ -183,7 +199,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
     const bool tail = dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr &&
                       dc3.b != nullptr && dc0.b != nullptr;
     const bool tail_dc0 = tail && dcb_tail_takes_dc0() && in.p != y.p;      // reads neighbours' input: not in place
-    if (!tail_dc0) {   // dc.0 + WSiLU
+    if (!tail_dc0 && !dc0_done) {   // dc.0 + WSiLU
         Conv1x1Desc d;
         d.x = in.p; d.ldx = in.ld; d.w = dc0.w; d.bias = dc0.b; d.wsilu = true;
         d.y = s.t1; d.ldy = cdc; d.pixels = P; d.cin = c; d.cout = cdc;
@@ -201,6 +217,18 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         return;
     }
     dwconv3x3(s.t1, cdc, dw, s.t2, cdc, H, W, cdc, st);
+    if (core_fused()) {
+        // dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) in one launch, intermediates in registers
+        DcbCoreDesc d;
+        d.t2 = s.t2; d.ldt = cdc; d.x = in.p; d.ldx = in.ld;
+        d.w3 = dc3.w; d.b3 = dc3.b; d.w0 = ffn0.w; d.b0 = ffn0.b; d.w2 = ffn2.w; d.b2 = ffn2.b;
+        d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.shortcut = shortcut;
+        if (next != nullptr) {
+            d.w1n = next->dc0.w; d.b1n = next->dc0.b; d.t1n = s.t1; d.ldt1 = next->cdc;
+        }
+        dcb_core(d, st);
+        return;
+    }
     {   // dc.3 (+ folded depthwise bias) + shortcut
         Conv1x1Desc d;
         d.x = s.t2; d.ldx = cdc; d.w = dc3.w; d.bias = dc3.b; d.r1 = in.p; d.ldr1 = in.ld;
@@ -320,10 +348,10 @@ void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& 
 }
 
 void UpsampleW::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
-                        half_t* up_tmp, const half_t* zeros) const
+                        half_t* up_tmp, const half_t* zeros, const DcbW* next) const
 {
     up.forward(x, tmp, H, W, st, up_tmp, zeros);
-    block.forward(tmp, y, 2 * H, 2 * W, s, st, shortcut);
+    block.forward(tmp, y, 2 * H, 2 * W, s, st, shortcut, nullptr, nullptr, View(), next);
 }
 
 void DcbChain::load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix)
@@ -341,9 +369,13 @@ void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, i
 {
     if (tmp2.p == nullptr) {
         View cur = x;
+        bool handed = false;            // the previous block left this block's dc.0 output in s.t1
         for (int i = 0; i < n; ++i) {
             const View out = (i == n - 1) ? y : tmp;
-            blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr);
+            const DcbW* next = (i + 1 < n && blocks[i].feeds(blocks[i + 1])) ? &blocks[i + 1] : nullptr;
+            blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr, nullptr, View(),
+                              next, handed);
+            handed = next != nullptr;
             cur = out;
         }
         return;

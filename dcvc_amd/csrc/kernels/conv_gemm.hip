@@ -683,12 +683,6 @@ void conv1x1(const Conv1x1Desc& d, hipStream_t stream)
         if (!d.bias || nres || d.q || d.q2 || d.cout % 256 != 0) {
             throw std::invalid_argument("conv1x1: chunk-add needs bias, no residual/quant, N % 256 == 0");
         }
-#ifdef DCVC_WITH_GEMM_PIPE      // build variant "pipe" only (dcvc_amd/build.py): the software-pipelined experiment
-        if (d.wsilu && gemm_pipe_enabled() && gemm_pipe_supported(d.pixels, d.cin, d.cout)) {
-            conv1x1_wsilu_chunk_pipe(d, stream);
-            return;
-        }
-#endif
         if (d.wsilu) launch<false, ACT_WSILU, true, 0, false, false>(p, stream);
         else         launch<false, ACT_NONE, true, 0, false, false>(p, stream);
         return;

@@ -56,11 +56,25 @@ struct Conv1x1Desc {
 };
 void conv1x1(const Conv1x1Desc& d, hipStream_t stream);
 
-// EXPERIMENT (build variant "pipe", gemm_pipe.hip): conv1x1 + bias + WSiLU + chunk-add with the epilogue
-// of one channel tile running inside the main loop of the next; bit-identical to conv1x1().
-bool gemm_pipe_enabled();                                       // DCVC_GEMM_PIPE=1
-bool gemm_pipe_supported(int pixels, int cin, int cout);
-void conv1x1_wsilu_chunk_pipe(const Conv1x1Desc& d, hipStream_t stream);
+// Full-width DepthConvBlock (C = 384) behind its depthwise conv in one launch (dcb_core.hip):
+//   y1 = W3 t2 + b3 + x ; t = chunk_add(WSiLU(W0 y1 + b0)) ; y = (W2 t + b2 + y1 [+ x]) [* q] -> fp16 [* q2]
+//   and optionally the next block's dc.0: t1n = WSiLU(W1n y + b1n).
+// Bit-identical to conv1x1(dc.3) + conv1x1(ffn.0, wsilu, chunk_add) + conv1x1(ffn.2) [+ conv1x1(dc.0, wsilu)].
+struct DcbCoreDesc {
+    const half_t* t2 = nullptr; int ldt = 0;    // depthwise output [pixels][ldt]
+    const half_t* x = nullptr; int ldx = 0;     // block input (residual of dc.3; of ffn.2 too when shortcut)
+    const half_t* w3 = nullptr; const half_t* b3 = nullptr;     // dc.3 [c][c], folded bias
+    const half_t* w0 = nullptr; const half_t* b0 = nullptr;     // ffn.0 [4c][c]
+    const half_t* w2 = nullptr; const half_t* b2 = nullptr;     // ffn.2 [c][c]
+    const half_t* q = nullptr; const half_t* q2 = nullptr;      // scales fused / applied to the rounded output
+    const half_t* w1n = nullptr; const half_t* b1n = nullptr;   // next block's dc.0 (optional)
+    half_t* t1n = nullptr; int ldt1 = 0;                        // its output [pixels][ldt1]
+    half_t* y = nullptr; int ldy = 0;           // may alias x when !shortcut (a wave reads and writes only its own pixels)
+    int pixels = 0, c = 0;
+    bool shortcut = false;
+};
+bool dcb_core_supported(int c, int cdc, int cffn);
+void dcb_core(const DcbCoreDesc& d, hipStream_t stream);
 
 struct ConvKxKDesc {
     const half_t* x = nullptr; int ldx = 0;     // [in_h][in_w][ldx]

@@ -125,6 +125,10 @@ inline int8_t dec_symbol(DecState& s, const CdfTable& t, int cdf_idx)
         while (g == kBypassMax) {
             g = dec_bits(s);
             n_groups += g;
+            if (n_groups > 16) {
+                // an int8 payload needs at most 4 groups; a damaged stream must not shift by >= 32
+                throw std::runtime_error("rANS decoder: corrupt escape code");
+            }
         }
         uint32_t raw = 0;
         for (uint32_t j = 0; j < n_groups; ++j) {
@@ -245,8 +249,16 @@ void WorkerPool::loop(int)
             const int item = m_next++;
             const auto* fn = m_fn;
             lk.unlock();
-            (*fn)(item);
+            std::exception_ptr err;
+            try {
+                (*fn)(item);
+            } catch (...) {
+                err = std::current_exception();
+            }
             lk.lock();
+            if (err && !m_error) {
+                m_error = err;
+            }
             if (--m_pending == 0) {
                 m_cv_done.notify_all();
             }
@@ -271,23 +283,42 @@ void WorkerPool::run(int n, const std::function<void(int)>& fn)
     m_n = n;
     m_next = 1;          // item 0 runs on the calling thread
     m_pending = n;
+    m_error = nullptr;
     ++m_epoch;
     lk.unlock();
     m_cv_work.notify_all();
-    fn(0);
+    // a failing item (bad_alloc, corrupt stream) must neither terminate a pool thread nor leave
+    // run() before every item has finished with the caller's buffers: first error wins, rethrown below
+    auto guarded = [&](int item) {
+        try {
+            fn(item);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m_err_mu);
+            if (!m_local_error) m_local_error = std::current_exception();
+        }
+    };
+    m_local_error = nullptr;
+    guarded(0);
     lk.lock();
     --m_pending;
     // help with whatever the workers have not picked up yet
     while (m_next < m_n) {
         const int item = m_next++;
         lk.unlock();
-        fn(item);
+        guarded(item);
         lk.lock();
         --m_pending;
     }
     m_cv_done.wait(lk, [&] { return m_pending == 0; });
     m_fn = nullptr;
     m_n = 0;
+    std::exception_ptr err = m_local_error ? m_local_error : m_error;
+    m_error = nullptr;
+    m_local_error = nullptr;
+    lk.unlock();
+    if (err) {
+        std::rethrow_exception(err);
+    }
 }
 
 // ------------------------------------------------------------------------ RansEncoder

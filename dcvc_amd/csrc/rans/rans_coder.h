@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -55,6 +56,8 @@ private:
     int m_n = 0, m_next = 0, m_pending = 0;
     uint64_t m_epoch = 0;
     bool m_stop = false;
+    std::exception_ptr m_error, m_local_error;      // first failure of a run(), rethrown by run()
+    std::mutex m_err_mu;
 };
 
 class RansEncoder {

@@ -57,7 +57,11 @@ def _bit_estimator_cdf(h, b, a):
     """Factorised prior of z: restates BitEstimator.update (entropy_models.py:113-149) incl.
     bit_estimator_z_prob (layers.py:13-19)."""
     import torch.nn.functional as F
-    h, b, a = h.float().cpu(), b.float().cpu(), a.float().cpu()
+    # on the parameters' own device, like the reference (update() runs on whatever device the
+    # model lives on): softplus / tanh / sigmoid may differ in the last place between devices,
+    # which can move a 0.001 / 0.999 range cut or a quantised frequency
+    dev = h.device
+    h, b, a = h.float(), b.float(), a.float()
     qp_num, channel, _ = h.shape
 
     def prob(x):
@@ -67,23 +71,23 @@ def _bit_estimator_cdf(h, b, a):
                 x = x + torch.tanh(x) * torch.tanh(a[:, :, i:i + 1, None])
         return torch.sigmoid(x)
 
-    zeros = torch.zeros((qp_num, channel, 1, 1))
+    zeros = torch.zeros((qp_num, channel, 1, 1), device=dev)
     sym_range = zeros + MAX_ENTROPY_CODING_VALUE
     for i in range(MAX_ENTROPY_CODING_VALUE, 1, -1):
         neg, pos = prob(zeros - i), prob(zeros + i)
         sym_range = torch.where(torch.logical_and(neg < 0.001, pos > 0.999),
-                                torch.tensor(float(i)), sym_range)
+                                torch.tensor(float(i), device=dev), sym_range)
     sym_range = sym_range.int()
     pmf_length = sym_range * 2 + 1
     max_length = MAX_ENTROPY_CODING_VALUE * 2 + 1
-    samples = torch.arange(max_length)[None, None, None, :] - sym_range
+    samples = torch.arange(max_length, device=dev)[None, None, None, :] - sym_range
     lower, upper = prob(samples - 0.5), prob(samples + 0.5)
     pmf = (upper - lower)[:, :, 0, :]
     upper_r = prob(sym_range.float())
     tail_mass = lower[:, :, 0, :1] + (1.0 - upper_r[:, :, 0, -1:])
-    pmf = pmf.reshape([-1, max_length])
-    tail_mass = tail_mass.reshape([-1, 1])
-    pmf_length = pmf_length.reshape([-1])
+    pmf = pmf.reshape([-1, max_length]).cpu()
+    tail_mass = tail_mass.reshape([-1, 1]).cpu()
+    pmf_length = pmf_length.reshape([-1]).cpu()
     cdf = _pmf_to_cdf(pmf, tail_mass, pmf_length, max_length)
     return cdf.numpy(), (pmf_length + 2).int().numpy()
 

@@ -63,6 +63,19 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
                    const void* r2, int ldr2, const void* q, const void* q2, void* y, int ldy,
                    int pixels, int c, int cffn, void* stream);
 
+/* A full-width DepthConvBlock (c = 384: the intra encoder / decoder) behind its depthwise conv in ONE
+ * launch (layers_proxy.cpp:81-98: conv1x1_bias_shortcut, conv1x1_bias_wsilu_chunk_add,
+ * conv1x1_bias_shortcut[2][_with_quant]), optionally followed by dc.0 of the NEXT block of a chain
+ * (conv1x1_bias_wsilu, layers_proxy.cpp:79):
+ *   y1 = W3 * t2 + b3 + x;  y = (W2 * chunk_add(WSiLU(W0 * y1 + b0)) + b2 + y1 [+ x]) [* q] -> fp16 [* q2];
+ *   t1n = WSiLU(W1n * y + b1n)   (when w1n != NULL).
+ * t2 = depthwise output [pixels][ldt], x = block input [pixels][ldx], b3 = dc.3 bias with the
+ * depthwise bias folded in. Bit-identical to the separate launches; y may alias x when !shortcut. */
+int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
+                  const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                  const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
+                  int pixels, int c, int shortcut, void* stream);
+
 /* DepthConvBlockProxy::forward behind dc.0 (layers_proxy.cpp:79-98: d3x3, conv1x1_bias_shortcut,
  * conv1x1_bias_wsilu_chunk_add, conv1x1_bias_shortcut[2][_with_quant]) in one launch for the
  * half-width blocks of the inter models: t = dc.0 output [H*W][ldt]; dw = [9][cdc] tap-major depthwise

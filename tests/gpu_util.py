@@ -42,6 +42,8 @@ class Ops:
         self.ffn_fused = _f("dcvc_ffn_fused", [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp])
         self.dcb_tail = _f("dcvc_dcb_tail", [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci,
                                              ci, ci, ci, ci, ci, ci, vp])
+        self.dcb_core = _f("dcvc_dcb_core", [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci,
+                                             ci, ci, ci, vp])
         self.scale_clamped = _f("dcvc_scale_clamped", [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp])
 
 

@@ -1,0 +1,127 @@
+"""HIP codecs against ORACLE-derived digests at BASELINE's own picture sizes (-m gpu).
+
+tests/golden/fullsize_digests.json holds the sha256 of everything the small live-oracle tests
+compare (rANS bytes, y, z, y_hat, temporal state, reconstructions), computed offline by the CPU
+oracle at 256x256 (BASELINE configs[0] tile), 1280x720 and 1920x1080
+(tests/golden/make_fullsize_digests.py). At these sizes the product takes the paths the small
+tests never reach: 256-row GEMM tiles, several rANS sub-streams, H16 padding (1080 -> 1088).
+Bar: bit-exact, like everywhere else."""
+import copy
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from codec_util import (chunk, dmc_ht_model, dmc_ld_model, dmci_model, from_device_output, picture,
+                        to_device_input)
+
+pytestmark = pytest.mark.gpu
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_digests.json")
+with open(_PATH) as _f:
+    DIGESTS = json.load(_f)
+
+
+def sha(a):
+    if isinstance(a, (bytes, bytearray)):
+        return hashlib.sha256(bytes(a)).hexdigest()
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _weights_digest(model):
+    h = hashlib.sha256()
+    sd = model.state_dict()
+    for k in sorted(sd):
+        a = sd[k].detach().cpu().numpy()
+        if a.dtype.kind == "f":
+            a = a.astype(np.float16)
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(a).tobytes())
+    for t in model.get_cdf_info():
+        h.update(np.ascontiguousarray(t.numpy() if hasattr(t, "numpy") else t).tobytes())
+    return h.hexdigest()
+
+
+def _gpu_net(model):
+    g = copy.deepcopy(model).half().cuda()      # finalize_model, test_video.py:27-29
+    g.proxy = None
+    return g
+
+
+def _padded(x):
+    h, w, _ = x.shape
+    return np.pad(x, ((0, -h % 16), (0, -w % 16), (0, 0)), mode="edge")
+
+
+def _same_inputs(want, got, what):
+    # the digests are only meaningful for the very same synthetic data: a host whose numpy / torch
+    # build generates different pictures or weights must not be reported as a codec mismatch
+    assert want == got, ("synthetic %s differ from the ones the digests were made from "
+                         "(tests/golden/make_fullsize_digests.py): not a codec result" % what)
+
+
+_DMCI = sorted(k for k, v in DIGESTS.items() if v["kind"] == "dmci")
+_INTER = sorted(k for k, v in DIGESTS.items() if v["kind"] != "dmci")
+
+
+@pytest.mark.parametrize("name", _DMCI)
+def test_intra_matches_oracle_digest(name):
+    d = DIGESTS[name]
+    hw, qp = (d["height"], d["width"]), d["qp"]
+    m = dmci_model(skip_thres=d["skip_thres"])
+    _same_inputs(d["weights"], _weights_digest(m), "weights")
+    x = picture(hw[0], hw[1], index=d["index"])
+    _same_inputs(d["input"], sha(x), "pictures")
+    g = _gpu_net(m)
+    pr, pb = g.get_padding_size(hw[0], hw[1], 16)
+    got = g.compress(to_device_input(x), qp, pb, pr)
+    torch.cuda.synchronize()
+    assert sha(g.proxy.debug_read("z_i8", np.int8)) == d["z_i8"], "z"
+    assert sha(g.proxy.debug_read("y", np.float16)) == d["y"], "y"
+    assert sha(g.proxy.debug_read("y_hat", np.float16)) == d["y_hat"], "y_hat"
+    assert got["ec_parallel"] == d["ec_parallel"]
+    assert len(got["bit_stream"]) == d["bytes"]
+    assert sha(got["bit_stream"]) == d["bit_stream"], "rANS bytes differ from the oracle's"
+    assert sha(from_device_output(got["x_hat"])) == d["x_hat"], "encoder-side reconstruction"
+    dec = _gpu_net(m)                                   # a decoder that never saw the picture
+    out = dec.decompress(got["bit_stream"], {"height": hw[0], "width": hw[1]}, qp, got["ec_parallel"])
+    torch.cuda.synchronize()
+    assert sha(from_device_output(out["x_hat"])) == d["x_hat"], "decoder-side reconstruction"
+
+
+@pytest.mark.parametrize("name", _INTER)
+def test_inter_matches_oracle_digest(name):
+    d = DIGESTS[name]
+    kind, hw = d["kind"], (d["height"], d["width"])
+    m = dmc_ld_model(skip_thres=d["skip_thres"]) if kind == "ld" else dmc_ht_model(kind, skip_thres=d["skip_thres"])
+    _same_inputs(d["weights"], _weights_digest(m), "weights")
+    ref = _padded(picture(hw[0], hw[1], index=0))
+    _same_inputs(d["ref"], sha(ref), "pictures")
+    enc, dec = _gpu_net(m), _gpu_net(m)
+    enc.add_ref_feature_from_frame(to_device_input(ref))
+    dec.add_ref_feature_from_frame(to_device_input(ref), apply_feature_adaptor=False)
+    for nm, want in d["state0"].items():
+        assert sha(enc.proxy.debug_read(nm, np.float16)) == want, nm
+    pr, pb = enc.get_padding_size(hw[0], hw[1], 16)
+    sps = {"height": hw[0], "width": hw[1]}
+    for i, c in enumerate(d["calls"]):
+        x = picture(hw[0], hw[1], index=i + 1) if kind == "ld" else chunk(hw[0], hw[1], 1 + 8 * i)
+        _same_inputs(c["input"], sha(x), "pictures")
+        got = enc.compress(to_device_input(x), c["qp"], c["reset"], pb, pr)
+        torch.cuda.synchronize()
+        assert sha(enc.proxy.debug_read("z_i8", np.int8)) == c["z_i8"], (i, "z")
+        assert sha(enc.proxy.debug_read("y", np.float16)) == c["y"], (i, "y")
+        assert sha(enc.proxy.debug_read("y_hat", np.float16)) == c["y_hat"], (i, "y_hat")
+        assert got["ec_parallel"] == c["ec_parallel"] and len(got["bit_stream"]) == c["bytes"]
+        assert sha(got["bit_stream"]) == c["bit_stream"], "call %d: rANS bytes differ from the oracle's" % i
+        for nm in ("feature_p", "memory", "ctx"):
+            assert sha(enc.proxy.debug_read(nm, np.float16)) == c[nm], (i, nm)
+        xd = dec.decompress(got["bit_stream"], sps, c["qp"], got["ec_parallel"], c["reset"])["x_hat"]
+        torch.cuda.synchronize()
+        xd = (np.concatenate([from_device_output(t) for t in xd], axis=-1) if isinstance(xd, (list, tuple))
+              else from_device_output(xd))
+        assert sha(xd) == c["x_hat"], "call %d: reconstruction differs from the oracle's" % i
+        assert sha(dec.proxy.debug_read("feature_p", np.float16)) == c["feature_p"], (i, "decoder feature_p")

@@ -480,36 +480,66 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
 
 
-@pytest.mark.parametrize("P,C,N,ldx_extra", [
-    (128 * 3, 384, 256, 0),          # one channel tile: prologue + tail only
-    (128 * 2 + 5, 384, 512, 64),     # two tiles, ragged last pixel tile, x a channel slice
-    (1000, 384, 1536, 0),            # the intra ffn.0 shape (6 tiles: both accumulator sets, steady state)
-    (777, 512, 2048, 0),             # K = 512 (HT full-width ffn.0), 8 tiles
-    (32640, 384, 1536, 0),           # 1080p
+@pytest.mark.parametrize("P,shortcut,quant,q2,nxt,inplace", [
+    (128, False, False, False, False, False),       # one workgroup
+    (300, False, False, False, True, True),         # ragged last workgroup, in place, next dc.0 fused
+    (1000, True, True, False, False, False),        # block shortcut + fused quant (not in place)
+    (2040, False, False, True, True, False),        # scale on the rounded output + next dc.0
+    (32640, False, False, False, True, True),       # 1080p P8 grid (255 workgroups), the chain configuration
+    (32640, True, False, True, False, False),
 ])
-def test_gemm_pipe_equals_conv_gemm(ops, P, C, N, ldx_extra):
-    """EXPERIMENT, build variant "pipe" only (DCVC_BUILD_VARIANT=pipe python -m dcvc_amd.build, then
-    DCVC_LIB=dcvc_amd/libdcvc_amd_pipe.so): the software-pipelined ffn.0 kernel (gemm_pipe.hip) gives
-    conv1x1(wsilu, chunk_add)'s output bit for bit. Skipped with the product library."""
-    import ctypes
-    from dcvc_amd import _lib
+def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inplace):
+    """dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) of a full-width DepthConvBlock in ONE launch
+    (dcb_core.hip) == conv1x1(dc.3, residual) -> conv1x1(ffn.0, wsilu, chunk_add) -> conv1x1(ffn.2,
+    residuals, quant) (-> conv1x1(dc.0, wsilu)), bit for bit; those launches are checked against
+    the oracle above."""
     from gpu_util import call, ptr, stream
-    try:
-        pipe = _lib.fn("dcvc_conv1x1_wsilu_chunk_pipe", ctypes.c_int,
-                       [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
-    except AttributeError:
-        pytest.skip("the loaded library is not the 'pipe' build variant")
-    dev = "cuda"
-    ld = C + ldx_extra
-    x = _rand((P, ld), 1.0, 201).to(dev)
-    w = (_rand((N, C), 1.0, 202) / C ** 0.5).half().to(dev)
-    b = _rand((N,), 0.3, 203).to(dev)
-    want = torch.zeros((P, N // 4), dtype=torch.half, device=dev)
-    got = torch.full((P, N // 4 + 8), 9.0, dtype=torch.half, device=dev)
-    call(ops.conv1x1, ptr(x), ld, ptr(w), ptr(b), None, 0, None, 0, None, None, ptr(want), N // 4, P, C, N, 3, stream())
-    call(pipe, ptr(x), ld, ptr(w), ptr(b), ptr(got), N // 4 + 8, P, C, N, stream())
+    dev, C = "cuda", 384
+    ldx = C + 64
+    xbuf = _rand((P, ldx), 1.0, 301).to(dev)
+    t2 = _rand((P, C), 1.0, 302).to(dev)
+    w3 = (_rand((C, C), 1.0, 303) / C ** 0.5).half().to(dev)
+    b3 = _rand((C,), 0.3, 304).to(dev)
+    w0 = (_rand((4 * C, C), 1.0, 305) / C ** 0.5).half().to(dev)
+    b0 = _rand((4 * C,), 0.3, 306).to(dev)
+    w2 = (_rand((C, C), 1.0, 307) / C ** 0.5).half().to(dev)
+    b2 = _rand((C,), 0.3, 308).to(dev)
+    w1 = (_rand((C, C), 1.0, 309) / C ** 0.5).half().to(dev)
+    b1 = _rand((C,), 0.3, 310).to(dev)
+    q = (_rand((C,), 0.2, 311) + 1.0).half().to(dev) if quant else None
+    qq = (_rand((C,), 0.2, 312) + 1.0).half().to(dev) if q2 else None
+    # the launch sequence
+    y1 = torch.zeros((P, C), dtype=torch.half, device=dev)
+    t = torch.zeros((P, C), dtype=torch.half, device=dev)
+    want = torch.zeros((P, C), dtype=torch.half, device=dev)
+    want_t1 = torch.zeros((P, C), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(t2), C, ptr(w3), ptr(b3), ptr(xbuf), ldx, None, 0, None, None, ptr(y1), C, P, C, C, 0, stream())
+    call(ops.conv1x1, ptr(y1), C, ptr(w0), ptr(b0), None, 0, None, 0, None, None, ptr(t), C, P, C, 4 * C, 3, stream())
+    call(ops.conv1x1, ptr(t), C, ptr(w2), ptr(b2), ptr(y1), C, ptr(xbuf) if shortcut else None, ldx, ptr(q), ptr(qq),
+         ptr(want), C, P, C, C, 0, stream())
+    call(ops.conv1x1, ptr(want), C, ptr(w1), ptr(b1), None, 0, None, 0, None, None, ptr(want_t1), C, P, C, C, 1, stream())
     torch.cuda.synchronize()
-    bad = int((got[:, :N // 4] != want).sum())
-    assert bad == 0, "%d of %d outputs differ" % (bad, want.numel())
-    assert (got[:, N // 4:] == 9.0).all()
+    # one launch
+    if inplace:
+        ybuf, ldy = xbuf.clone(), ldx
+        xin = ybuf
+    else:
+        ybuf, ldy = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev), C + 8
+        xin = xbuf
+    t1 = torch.full((P, C + 8), 7.0, dtype=torch.half, device=dev)
+    call(ops.dcb_core, ptr(t2), C, ptr(xin), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), ptr(qq),
+         ptr(w1) if nxt else None, ptr(b1) if nxt else None, ptr(t1) if nxt else None, C + 8, ptr(ybuf), ldy,
+         P, C, 1 if shortcut else 0, stream())
+    torch.cuda.synchronize()
+    bad = int((ybuf[:, :C] != want).sum())
+    assert bad == 0, "y: %d of %d outputs differ" % (bad, want.numel())
+    if inplace:
+        assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
+    else:
+        assert (ybuf[:, C:] == 9.0).all()
+    if nxt:
+        bad = int((t1[:, :C] != want_t1).sum())
+        assert bad == 0, "next dc.0: %d of %d outputs differ" % (bad, want_t1.numel())
+        assert (t1[:, C:] == 7.0).all()
+    else:
+        assert (t1 == 7.0).all()
