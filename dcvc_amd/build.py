@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libdcvc_amd.so")
 
 COMMON = [
-    "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
+    "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-inline-asm",
     # arithmetic policy: no fast-math, no implicit contraction - every fma is spelled fmaf()
     # so that the CPU oracle can reproduce the device arithmetic bit for bit.
     "-ffp-contract=off", "-fno-fast-math",

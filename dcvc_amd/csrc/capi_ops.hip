@@ -239,6 +239,11 @@ int dcvc_gemm_timeline_buffer(void* device_buffer)
     return dcvc::guarded([&] { dcvc::gemm_timeline_buffer(static_cast<long long*>(device_buffer)); });
 }
 
+int dcvc_dcb_core_timeline_buffer(void* device_buffer)
+{
+    return dcvc::guarded([&] { dcvc::dcb_core_timeline_buffer(static_cast<long long*>(device_buffer)); });
+}
+
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream)
 {
     return dcvc::guarded([&] {

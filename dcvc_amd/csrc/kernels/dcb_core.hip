@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <stdexcept>
+#include <type_traits>
 
 namespace dcvc {
 
@@ -42,17 +43,42 @@ namespace {
 constexpr int C = 384;                   // block width
 constexpr int NTHREADS = 256;
 constexpr int BM = 128;                  // pixels per workgroup
-constexpr int SLAB = 128 * 64 * 2;       // [128 channels][64 k] fp16 = 16 KB
-constexpr int NS = 5;                    // ring slots (15 slabs per ffn super-chunk: slot indices stay static)
+constexpr int SLAB = 16384;              // one weight slab: [128 channels][64 k] or [64 channels][128 k] fp16
+constexpr int NS = 5;                    // ring slots (the 15 slabs of a loop body map onto fixed slots)
 constexpr int LPS = SLAB / (NTHREADS * 16);   // global_load_lds per thread and slab = 4
 constexpr int R = 4;                     // interleaved copies of the WSiLU table
 constexpr int TABLE_BYTES = WSILU_SEGMENTS * 16;
 constexpr int OFF_TABLE = NS * SLAB;
-constexpr int OFF_STAGE = OFF_TABLE + R * TABLE_BYTES;
-constexpr int STAGE_BYTES = 32 * 256;    // per wave: 32 pixels x 128 channels fp16
-constexpr int SMEM_BYTES = OFF_STAGE + 4 * STAGE_BYTES;
-constexpr int G_A = 18, G_B = 90, G_D = 18;      // slabs of dc.3 / ffn.0+ffn.2 / next dc.0
-static_assert(15 % NS == 0, "a super-chunk of 15 slabs must map onto the same ring slots every time");
+constexpr int OFF_CONST = OFF_TABLE + R * TABLE_BYTES;    // b3 | b0 | b2 | b1n | q | q2, fp16
+constexpr int CONST_HALVES = C + 4 * C + C + C + C + C;
+constexpr int OFF_SLABS = OFF_CONST + CONST_HALVES * 2;    // weight stream: address | shape of every slab, 8 B each
+constexpr int SLAB_ENTRIES = 136;
+constexpr int OFF_STAGE = OFF_SLABS + SLAB_ENTRIES * 8;
+// per wave: [finished accumulator pair, 32 floats per lane, lane-linear 16-B units: 8 KB][64-channel output rows]
+// the 128-channel output rows of the ffn.2 epilogue reuse the front of the area (nothing else is live then)
+constexpr int DUMP_BYTES = 8 * 1024;
+constexpr int PITCH128 = 256 + 16, PITCH64 = 128 + 16;   // staged output rows are padded, not swizzled
+constexpr int WAVE_AREA = DUMP_BYTES + 32 * PITCH64;
+static_assert(32 * PITCH128 <= WAVE_AREA, "ffn.2 output rows must fit the wave's area");
+constexpr int SMEM_BYTES = OFF_STAGE + 4 * WAVE_AREA;
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+// the weight stream (slab index g):
+//   [0, 18)     dc.3, wide slabs, k-step outer / 128-channel chunk inner
+//   [18, 30)    ffn.0 of super-chunk 0: 4 channel pairs x 3 deep slabs
+//   [30, 105)   super-chunks 1..5, 15 slabs each: pair 0 | ffn.2 of the previous super-chunk (3 wide) | pairs 1..3
+//   [105, 108)  ffn.2 of super-chunk 5
+//   [108, 126)  dc.0 of the next block: 6 channel pairs x 3 deep slabs (optional)
+constexpr int G_A = 18, G_B0 = 12, G_LOOP = 75, G_F5 = 3, G_D = 18;
+constexpr int G_CORE = G_A + G_B0 + G_LOOP + G_F5;
+static_assert(15 % NS == 0 && (G_A + G_B0) % NS == 0, "the loop body must start on slot 0 every time");
+static_assert(G_CORE + G_D + NS <= SLAB_ENTRIES, "slab table too small");
+
+#ifndef DCB_CORE_NO_FENCE
+#define SLICE_FENCE() __builtin_amdgcn_sched_barrier(0)      // the schedule is hand-made: nothing crosses a k-slice
+#else
+#define SLICE_FENCE()
+#endif
+enum : int { WIDE = 0, DEEP = 1 };       // slab shapes: [128 rows][64 k] (4 tiles x 4 k-slices) / [64 rows][128 k] (2 x 8)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -70,8 +96,41 @@ struct CoreParams {
     half_t* t1n;          // [M][ldt1] (with w1n)
     int ldt, ldx, ldy, ldt1;
     int M, shortcut;
+    long long* timeline;  // optional [workgroups][64] shader-clock stamps of wave 0 (tools/core_timeline.py)
 };
 
+// One LDS-DMA piece (64 lanes x 16 B, lane l lands at lds_dst + 16 l) issued behind the compiler's back.
+// With the builtin, hipcc's wait-count pass puts s_waitcnt vmcnt(0) in front of the next LDS read that
+// might alias the destination - it cannot tell the ring from the WSiLU table, so every table gather of
+// the interleaved epilogue drained the whole prefetch (measured: 2700 cycles per 16 KB slab). The
+// ordering that matters is enforced by hand: counted vmcnt + s_barrier at the top of every step.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+
+template <int N, int RR>
+__device__ __forceinline__ void wsilu_n(float (&v)[N], const float4* tab)
+{
+    float f[N];
+    float4 c[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        float t = fmaf(v[e], 16.0f, 128.0f);
+        t = fminf(fmaxf(t, 0.0f), 255.99998f);
+        f[e] = __builtin_amdgcn_fractf(t);
+        c[e] = tab[static_cast<int>(t) * RR];
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        float pp = fmaf(c[e].w, f[e], c[e].z);
+        pp = fmaf(pp, f[e], c[e].y);
+        pp = fmaf(pp, f[e], c[e].x);
+        v[e] = v[e] * pp;
+    }
+}
+
+template <bool TIMELINE>
 __global__ void __launch_bounds__(NTHREADS, 1)
 dcb_core_kernel(const CoreParams p)
 {
@@ -83,42 +142,118 @@ dcb_core_kernel(const CoreParams p)
     const int px = lane & 31;
     const int hi = lane >> 5;
     const int m0 = blockIdx.x * BM + wave * 32;
-    const int m = m0 + px;                       // this lane's pixel
-    const int mc = min(m, p.M - 1);              // clamped for loads
-    const int G = G_A + G_B + (p.w1n != nullptr ? G_D : 0);
+    const int mc = min(m0 + px, p.M - 1);        // this lane's pixel, clamped for loads
+    const int G = G_CORE + (p.w1n != nullptr ? G_D : 0);
 
-    // ---- weight stream: slab g -> (matrix, first row, first k). Every matrix has row stride C.
-    auto slab_base = [&](int g) -> const half_t* {
-        if (g < G_A) {      // dc.3: k-step outer, channel chunk inner
+    const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)smem));   // LDS byte address of the ring
+    // ---- weight stream: slab g -> first element and shape. Every matrix has row stride C.
+    auto slab_info = [&](int g, int& shape) -> const half_t* {
+        if (g < G_A) {                       // dc.3: k-step outer, 128-channel chunk inner
+            shape = WIDE;
             return p.w3 + static_cast<size_t>(g % 3) * (128 * C) + (g / 3) * 64;
         }
         g -= G_A;
-        if (g < G_B) {
-            const int sc = g / 15, r = g - sc * 15;
-            if (r < 12) {
-                return p.w0 + static_cast<size_t>(sc * 256 + (r / 6) * 128) * C + (r % 6) * 64;
-            }
-            return p.w2 + static_cast<size_t>(r - 12) * (128 * C) + sc * 64;
+        if (g < G_B0) {                      // ffn.0, super-chunk 0: pair g/3, k third g%3
+            shape = DEEP;
+            return p.w0 + static_cast<size_t>(g / 3) * (64 * C) + (g % 3) * 128;
         }
-        g -= G_B;
-        return p.w1n + static_cast<size_t>(g / 6) * (128 * C) + (g % 6) * 64;
+        g -= G_B0;
+        if (g < G_LOOP) {
+            const int sc = 1 + g / 15, r = g % 15;
+            if (r >= 3 && r < 6) {           // ffn.2 of super-chunk sc-1: 128-channel chunk r-3
+                shape = WIDE;
+                return p.w2 + static_cast<size_t>(r - 3) * (128 * C) + (sc - 1) * 64;
+            }
+            const int pair = r < 3 ? 0 : 1 + (r - 6) / 3;
+            const int k3 = r < 3 ? r : (r - 6) % 3;
+            shape = DEEP;
+            return p.w0 + static_cast<size_t>(sc * 256 + pair * 64) * C + k3 * 128;
+        }
+        g -= G_LOOP;
+        if (g < G_F5) {
+            shape = WIDE;
+            return p.w2 + static_cast<size_t>(g) * (128 * C) + 5 * 64;
+        }
+        g -= G_F5;
+        shape = DEEP;
+        return p.w1n + static_cast<size_t>(g / 3) * (64 * C) + (g % 3) * 128;
     };
-    // staging plan (conv_gemm.hip): 16-B unit u = j*256 + tid -> slab row u>>3, physical chunk u&7,
-    // logical chunk = physical ^ ((row>>1)&7); the LDS image is lane-linear
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-    const int toff = srow * C + schunk * 8;      // + j * 32 rows
-    auto issue_slab = [&](int g, int slot) {
-        if (g < G) {
-            const half_t* base = slab_base(g) + toff;
-            char* dst = smem + slot * SLAB;
+    // staging: the LDS image of a slab is lane-linear (16-B unit u = j*256 + tid), so the bank swizzle
+    // sits on the SOURCE side. wide: row u>>3, chunk (u&7) ^ ((row>>1)&7); deep: row u>>4, chunk (u&15) ^ (row&15)
+    const int toff_w = (tid >> 3) * C + ((tid & 7) ^ ((tid >> 4) & 7)) * 8;     // + j * 32 rows
+    const int toff_d = (tid >> 4) * C + ((tid & 15) ^ ((tid >> 4) & 15)) * 8;   // + j * 16 rows
+    // The stream is tabulated once (LDS, address | shape in bit 0) so that the steady state has no
+    // control flow at all; entries behind the last slab repeat it: the prefetch of "slab g+4" and the
+    // counted waits then stay uniform to the very end (a few KB of redundant loads, drained at exit).
+    unsigned long long* ltbl = reinterpret_cast<unsigned long long*>(smem + OFF_SLABS);
+    if (tid < SLAB_ENTRIES) {
+        int shape = WIDE;
+        const half_t* base = slab_info(min(tid, G - 1), shape);
+        ltbl[tid] = reinterpret_cast<unsigned long long>(base) | static_cast<unsigned long long>(shape);
+    }
+    struct Pending { const half_t* src; int jstride; unsigned dst; };
+    auto plan_slab = [&](int g, int slot) {
+        const unsigned long long e = ltbl[g];
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(e));
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(e >> 32));
+        const bool deep = (lo & 1u) != 0;
+        const half_t* base = reinterpret_cast<const half_t*>((static_cast<unsigned long long>(hi32) << 32) | (lo & ~1u));
+        Pending q;
+        q.src = base + (deep ? toff_d : toff_w);
+        q.jstride = deep ? 16 * C : 32 * C;
+        q.dst = lds_base + slot * SLAB + wave * 1024;
+        return q;
+    };
+    auto issue_part = [&](const Pending& q, int j) {
+        lds_dma16(q.src + j * q.jstride, q.dst + j * (NTHREADS * 16));
+    };
+
+    // ---- L2 warm-up. Every workgroup streams the SAME weights at the same time, and L2 starts cold
+    // at every kernel boundary: the first touch of a line misses for all 32 CUs of an XCD at once and
+    // they all sit out the Infinity-Cache round trip - with 48 KB in flight per CU that capped the
+    // stream at ~6-13 B/clk/CU (measured: 2700 cycles per 16 KB slab). So each workgroup first touches
+    // ITS share of the whole stream (line q belongs to the workgroup with (blockIdx / 8) % 32 == q % 32;
+    // blockIdx % 8 is the XCD): 2 loads per thread, all misses in flight together, and the demand
+    // loads behind them find their lines in L2.
+    unsigned warm = 0;
+    {
+        const int rank = (blockIdx.x >> 3) & 31;
+        constexpr int L3 = C * C / 64, L0 = 4 * C * C / 64;       // 128-B lines per matrix
+        const int total = L3 + L0 + L3 + (p.w1n != nullptr ? L3 : 0);
 #pragma unroll
-            for (int j = 0; j < LPS; ++j) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + j * (32 * C)),
-                                                 (lptr_t)(dst + (j * NTHREADS + wave * 64) * 16), 16, 0, 0);
+        for (int k = 0; k < 3; ++k) {
+            const int q = rank + 32 * (tid + NTHREADS * k);
+            if (q < total) {
+                const half_t* base = q < L3 ? p.w3 + static_cast<size_t>(q) * 64
+                                   : q < L3 + L0 ? p.w0 + static_cast<size_t>(q - L3) * 64
+                                   : q < 2 * L3 + L0 ? p.w2 + static_cast<size_t>(q - L3 - L0) * 64
+                                   : p.w1n + static_cast<size_t>(q - 2 * L3 - L0) * 64;
+                warm ^= *reinterpret_cast<const unsigned*>(base);
             }
         }
-    };
+    }
+
+    // ---- constants -> LDS (WSiLU table in R interleaved copies: lane l gathers from copy l & (R-1);
+    // biases and scales). Their global loads go out FIRST: vmcnt retires in order, so a register-
+    // destination load behind the weight prefetch drains the ring when it is waited for - for the
+    // same reason no such load sits inside the slab loop except where the count is exact.
+    constexpr int TAB_PER_THREAD = R * WSILU_SEGMENTS / NTHREADS;
+    float4 tabv[TAB_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < TAB_PER_THREAD; ++k) tabv[k] = p.wsilu[(tid + k * NTHREADS) / R];
+    constexpr int CONST_UNITS = CONST_HALVES / 8;        // 432 16-B units
+    half8 constv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int ch = min(tid + k * NTHREADS, CONST_UNITS - 1) * 8;
+        const half_t* src = ch < C ? p.b3 + ch
+                          : ch < 5 * C ? p.b0 + (ch - C)
+                          : ch < 6 * C ? p.b2 + (ch - 5 * C)
+                          : ch < 7 * C ? (p.b1n != nullptr ? p.b1n + (ch - 6 * C) : p.b2)
+                          : ch < 8 * C ? (p.q != nullptr ? p.q + (ch - 7 * C) : p.b2)
+                          : (p.q2 != nullptr ? p.q2 + (ch - 8 * C) : p.b2);
+        constv[k] = *reinterpret_cast<const half8*>(src);
+    }
 
     // ---- B fragments of this lane's pixel: k-slice i = channels 16 i + 8 hi .. + 7
     half8 bf[24];
@@ -128,70 +263,132 @@ dcb_core_kernel(const CoreParams p)
         for (int i = 0; i < 24; ++i) bf[i] = *reinterpret_cast<const half8*>(row + 16 * i);
     }
 #pragma unroll
-    for (int g = 0; g < NS - 1; ++g) issue_slab(g, g);
+    for (int g = 0; g < NS - 1; ++g) {        // slabs 0..3 are dc.3's (wide), straight from the matrix
+        int shape = WIDE;
+        Pending q;
+        q.src = slab_info(g, shape) + toff_w;
+        q.jstride = 32 * C;
+        q.dst = lds_base + g * SLAB + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) issue_part(q, j);
+    }
 
-    // WSiLU table -> LDS, R interleaved copies (lane l gathers from copy l & (R-1))
+    const float4* tab = reinterpret_cast<const float4*>(smem + OFF_TABLE) + (lane & (R - 1));
+    half_t* lconst = reinterpret_cast<half_t*>(smem + OFF_CONST);
     {
         float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
-        for (int i = tid; i < R * WSILU_SEGMENTS; i += NTHREADS) t[i] = p.wsilu[i / R];
-    }
-    const float4* tab = reinterpret_cast<const float4*>(smem + OFF_TABLE) + (lane & (R - 1));
-
-    // A-fragment offsets inside a slab for the four 16-wide k slices (conv_gemm.hip)
-    const int fsw = (px >> 1) & 7;
-    int foff[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) foff[s] = px * 128 + (((s * 2 + hi) ^ fsw) << 4);
-
-    // One slab: wait until it has landed, make sure every wave is done with the slot the next
-    // prefetch overwrites, prefetch, then 4 k-slices x 4 channel tiles of MFMAs. b(s) = the B
-    // fragment of k-slice s, acc(nt) = the accumulator of channel tile nt.
-    // `slot` = g % NS, passed separately so that it stays a compile-time constant wherever the caller
-    // knows it (g itself is a run-time value inside the rolled loops).
-    auto slab_step = [&](int g, int slot, auto&& bfrag, float16v (&acc)[4]) {
-        if (g + NS - 1 < G) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int k = 0; k < TAB_PER_THREAD; ++k) t[tid + k * NTHREADS] = tabv[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = tid + k * NTHREADS;
+            if (u < CONST_UNITS) *reinterpret_cast<half8*>(lconst + u * 8) = constv[k];
         }
+    }
+    const half_t* lb3 = lconst;
+    const half_t* lb0 = lconst + C;
+    const half_t* lb2 = lconst + 5 * C;
+    const half_t* lb1n = lconst + 6 * C;
+    const half_t* lq = lconst + 7 * C;
+    const half_t* lq2 = lconst + 8 * C;
+    int stamp_no = 0;
+    auto stamp = [&]() {
+        if (TIMELINE && tid == 0 && stamp_no < 64) {
+            p.timeline[static_cast<size_t>(blockIdx.x) * 64 + stamp_no] = static_cast<long long>(__builtin_readcyclecounter());
+        }
+        ++stamp_no;
+    };
+
+    // A-fragment offsets inside a slab (tile t adds 32 rows)
+    // One register per (shape, k-slice); slot and tile are compile-time byte offsets that fold into the
+    // ds_read immediate. (Anything computed per (slot, tile, slice) is loop-invariant and gets hoisted:
+    // 240 address registers in an earlier version of this kernel, i.e. spills all over the walk.)
+    int foff_w[4], foff_d[8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff_w[s] = (px * 128 + (((s * 2 + hi) ^ ((px >> 1) & 7)) << 4)) & 0xfff;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) foff_d[s] = (px * 256 + (((s * 2 + hi) ^ (px & 15)) << 4)) & 0x1fff;
+    // (the masks are no-ops that tell the compiler the bases are small and non-negative: without that
+    // knowledge it will not fold the slot offset into the ds_read immediate)
+    auto frag_w = [&](const char* ws, int tile, int s) { return *reinterpret_cast<const half8*>(ws + foff_w[s] + tile * 4096); };
+    auto frag_d = [&](const char* ws, int tile, int s) { return *reinterpret_cast<const half8*>(ws + foff_d[s] + tile * 8192); };
+
+    // slab 0 (and the constants) landed and visible; three more slabs stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();                                         // 0: first slab there
+    if (warm == 0x9e3779b9u && p.M < 0) p.y[0] = static_cast<half_t>(0);     // never true: keeps the warm-up loads alive
+    // One slab = 16 MFMAs per wave. The barrier at the top of step g certifies slab g+1 (every wave
+    // waited for its own share) and frees the slot of slab g-1 for the prefetch of slab g+4; slab g
+    // itself was certified one step earlier, so nothing waits between the barrier and the first reads.
+    // (Reading the first fragments of slab g+1 at the end of step g would hide one LDS round trip per
+    // step, but the 16 registers that then live across every step boundary push hipcc into spilling
+    // B fragments inside the walk - measured: 176 spilled registers with, 14 outside the loops without.)
+    // piece(s): VALU work (the epilogue of an EARLIER accumulator set) placed behind the MFMAs of k-slice s.
+    auto step_top = [&](int g, int slot) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issue_slab(g + NS - 1, (slot + NS - 1) % NS);
+        return plan_slab(g + NS - 1, (slot + NS - 1) % NS);
+    };
+    auto step_wide = [&](int g, int slot, int /*next_shape*/, auto&& bfrag, float16v (&acc)[4], auto&& piece) {
+        const Pending nx = step_top(g, slot);
         const char* ws = smem + slot * SLAB;
         half8 wf[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const half8*>(ws + nt * 4096 + foff[0]);
+        for (int nt = 0; nt < 4; ++nt) wf[0][nt] = frag_w(ws, nt, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < 3) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    wf[(s + 1) & 1][nt] = *reinterpret_cast<const half8*>(ws + nt * 4096 + foff[s + 1]);
+                for (int nt = 0; nt < 4; ++nt) wf[(s + 1) & 1][nt] = frag_w(ws, nt, s + 1);
             }
             const half8 b = bfrag(s);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], b, acc[nt], 0, 0, 0);
+            issue_part(nx, s);
+            piece(s);
+            SLICE_FENCE();
         }
     };
-
-    // accumulators of 4 channel tiles (128 channels from `first`) initialised with the bias:
-    // acc[nt][r] = channel first + 32 nt + 8 (r>>2) + 4 hi + (r&3)
-    auto bias_init = [&](float16v (&acc)[4], const half_t* bias, int first) {
+    auto step_deep = [&](int g, int slot, int /*next_shape*/, auto&& bfrag, float16v (&acc)[2], auto&& piece) {
+        const Pending nx = step_top(g, slot);
+        const char* ws = smem + slot * SLAB;
+        half8 wf[3][2];
+        wf[0][0] = frag_d(ws, 0, 0); wf[0][1] = frag_d(ws, 1, 0); wf[1][0] = frag_d(ws, 0, 1); wf[1][1] = frag_d(ws, 1, 1);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const half_t* bp = bias + first + 32 * nt + 4 * hi;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[nt][4 * g4 + e] = static_cast<float>(b4[e]);
+        for (int s = 0; s < 8; ++s) {
+            if (s + 2 < 8) {
+                wf[(s + 2) % 3][0] = frag_d(ws, 0, s + 2);
+                wf[(s + 2) % 3][1] = frag_d(ws, 1, s + 2);
             }
+            const half8 b = bfrag(s);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][0], b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][1], b, acc[1], 0, 0, 0);
+            if ((s & 1) == 0) issue_part(nx, s >> 1);
+            piece(s);
+            SLICE_FENCE();
+        }
+    };
+    auto no_piece = [](int) {};
+
+    // accumulator tile (32 channels from `first`) initialised with the bias:
+    // acc[r] = channel first + 8 (r>>2) + 4 hi + (r&3)
+    auto bias_tile = [&](float16v& acc, const half_t* bias, int first) {
+        const half_t* bp = bias + first + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g4 + e] = static_cast<float>(b4[e]);
         }
     };
     // accumulator tile -> the two 8-channel runs this lane owns after pairing the half-waves:
-    // run pr = channels 32 nt + 16 pr + 8 hi .. + 7 of the lane's pixel (= B-fragment layout)
+    // run pr = channels 16 pr + 8 hi .. + 7 of the tile, this lane's pixel (= B-fragment layout)
     auto runs_of = [&](const float16v& a, int pr, float (&v)[8]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -201,23 +398,27 @@ dcb_core_kernel(const CoreParams p)
             v[4 + e] = __uint_as_float(sw[1]);
         }
     };
-    // 128 output channels of the wave's 32 pixels -> memory in whole 256-B runs, via the wave's
+    // NCH output channels (64 or 128) of the wave's 32 pixels -> memory in whole rows, via the wave's
     // own staging area (no other wave touches it: wave-local ordering is enough)
-    char* stg = smem + OFF_STAGE + wave * STAGE_BYTES;
-    auto flush128 = [&](const half8 (&o)[8], half_t* dst, int ld, int first) {
+    char* const dump = smem + OFF_STAGE + wave * WAVE_AREA;
+    auto flush = [&](const half8* o, auto nch_tag, half_t* dst, int ld, int first) {
+        constexpr int NCH = decltype(nch_tag)::value;
+        constexpr int CPR = NCH / 8;                       // 16-B chunks per row
+        constexpr int STAGE_PITCH = NCH == 128 ? PITCH128 : PITCH64;
+        char* const stg = NCH == 128 ? dump : dump + DUMP_BYTES;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int cidx = 2 * i + hi;                   // (4 nt + 2 pr + hi), i = 2 nt + pr
-            *reinterpret_cast<half8*>(stg + px * 256 + ((cidx ^ (px & 15)) << 4)) = o[i];
+        for (int i = 0; i < CPR / 2; ++i) {                // run i = (tile i/2, pr i%2) -> channels 16 i + 8 hi
+            *reinterpret_cast<half8*>(stg + px * STAGE_PITCH + hi * 16 + i * 32) = o[i];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int RPI = 64 / CPR;                      // rows per iteration
+        const int rrow = lane / CPR, rc = lane % CPR;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int u = it * 64 + lane;
-            const int row = u >> 4, c16 = u & 15;
-            const half8 v = *reinterpret_cast<const half8*>(stg + row * 256 + ((c16 ^ (row & 15)) << 4));
+        for (int it = 0; it < CPR / 2; ++it) {
+            const int row = it * RPI + rrow;
+            const half8 v = *reinterpret_cast<const half8*>(stg + rrow * STAGE_PITCH + rc * 16 + it * (RPI * STAGE_PITCH));
             if (m0 + row < p.M) {
-                store_line(dst + static_cast<size_t>(m0 + row) * ld + first + c16 * 8, v);
+                store_line(dst + static_cast<size_t>(m0 + row) * ld + first + rc * 8, v);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -225,180 +426,243 @@ dcb_core_kernel(const CoreParams p)
 
     int g = 0;
     // ================================================================ dc.3: y1 = W3 t2 + b3' + x
-    // All 12 channel tiles accumulate at once (k-step outer, channel chunk inner) in the registers
-    // ffn.2's accumulators take over afterwards; the fp16 result then replaces t2 in `bf` in place.
+    // All 12 channel tiles accumulate at once in the registers ffn.2's accumulators take over
+    // afterwards; the fp16 result then replaces t2 in `bf` in place. The block input x arrives in the
+    // registers t2 frees up (one 128-channel third after each of the k-steps 2..4): behind each of those loads the
+    // number of younger memory operations is exact, so waiting for it does not drain the prefetch.
     float16v acc2[12];
-    {
-        float16v tmp[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            bias_init(tmp, p.b3, 128 * c);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc2[4 * c + nt] = tmp[nt];
-        }
-    }
+    for (int nt = 0; nt < 12; ++nt) bias_tile(acc2[nt], lb3, 32 * nt);
+    half8 xr[24];
+    const half_t* xrow = p.x + static_cast<size_t>(mc) * p.ldx + 8 * hi;
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float16v a4[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) a4[nt] = acc2[4 * c + nt];
-            slab_step(g, (3 * ks + c) % NS, [&](int s) { return bf[ks * 4 + s]; }, a4);
+            step_wide(g, (3 * ks + c) % NS, (ks == 5 && c == 2) ? DEEP : WIDE, [&](int s) { return bf[ks * 4 + s]; },
+                      *reinterpret_cast<float16v(*)[4]>(&acc2[4 * c]), no_piece);
             ++g;
+        }
+        if (ks >= 2 && ks <= 4) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc2[4 * c + nt] = a4[nt];
+            for (int i = 0; i < 8; ++i) xr[8 * (ks - 2) + i] = *reinterpret_cast<const half8*>(xrow + 128 * (ks - 2) + 16 * i);
         }
     }
-    {
-        const half_t* xrow = p.x + static_cast<size_t>(mc) * p.ldx + 8 * hi;
+    stamp();                                         // 1: dc.3 slabs done
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            half8 xr[8];
+    for (int nt = 0; nt < 12; ++nt)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const half8*>(xrow + 128 * c + 16 * i);
+        for (int pr = 0; pr < 2; ++pr) {
+            float v[8];
+            runs_of(acc2[nt], pr, v);
+            half8 o;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    float v[8];
-                    runs_of(acc2[4 * c + nt], pr, v);
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[2 * nt + pr][e]));
-                    // opaque: otherwise hipcc keeps every element a second time, unpacked, for the
-                    // residual add of the ffn.2 epilogue (192 values spilled across the ffn walk)
-                    asm volatile("" : "+v"(o));
-                    bf[8 * c + 2 * nt + pr] = o;
-                }
+            for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[2 * nt + pr][e]));
+            // opaque: otherwise hipcc keeps every element a second time, unpacked, for the
+            // residual add of the ffn.2 epilogue (192 values spilled across the ffn walk)
+            asm volatile("" : "+v"(o));
+            bf[2 * nt + pr] = o;
         }
-    }
 
     // ================================================================ ffn.0 -> t -> ffn.2 accumulators
-    {
-        float16v tmp[4];
+    // ffn.0 runs channel pair by channel pair (2 tiles x the whole K = 3 deep slabs): the WSiLU /
+    // chunk-add epilogue of a finished pair (8 pieces of 4 values + one combine -> ONE B fragment of
+    // t) is issued between the MFMAs of the following 3 slabs, matrix pipe and VALU side by side.
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            bias_init(tmp, p.b2, 128 * c);
+    for (int nt = 0; nt < 12; ++nt) bias_tile(acc2[nt], lb2, 32 * nt);
+    // A finished pair is parked in the wave's own LDS area (8 x 16-B units per lane, lane-linear) and
+    // its epilogue reads 4 values at a time from there: reading them out of the accumulator registers
+    // piecewise makes hipcc copy whole 16-register tuples to VGPRs for the duration (2 x 32 registers
+    // across the walk = spills in the inner loop, which in-order vmcnt turns into full pipeline drains).
+    float16v cur[2];
+    float sums[2][4];
+    auto park = [&](const float16v (&a)[2]) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc2[4 * c + nt] = tmp[nt];
-        }
-    }
-    for (int sc = 0; sc < 6; ++sc) {
-        half8 t3[4];
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float16v acc[4];
-            bias_init(acc, p.b0, sc * 256 + h * 128);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4v v4;
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                slab_step(g, (G_A + 6 * h + ks) % NS, [&](int s) { return bf[ks * 4 + s]; }, acc);   // 15 % NS == 0
-                ++g;
+                for (int e = 0; e < 4; ++e) v4[e] = a[hh][4 * g4 + e];
+                *reinterpret_cast<float4v*>(dump + (hh * 4 + g4) * 1024 + lane * 16) = v4;
             }
-            // z = wsilu(acc); sum of 4 adjacent channels ((z0+z1)+z2)+z3; pair the half-waves
+    };
+    auto parked = [&](int unit) { return *reinterpret_cast<const float4v*>(dump + unit * 1024 + lane * 16); };
+    half8 t3[4], t3n;
+    // epilogue piece q (0..7) of the pair in `prev`; q == 8: combine into a B fragment
+    auto ffn0_piece = [&](int q, half8& out) {
+        if (q < 8) {
+            const int hh = q >> 2, g4 = q & 3;
+            const float4v v4 = parked(q);
+            float v[4];
 #pragma unroll
-            for (int np = 0; np < 2; ++np) {
-                float sum[2][4];
+            for (int e = 0; e < 4; ++e) v[e] = v4[e];
+            wsilu_n<4, R>(v, tab);
+            sums[hh][g4] = ((v[0] + v[1]) + v[2]) + v[3];
+        } else if (q == 8) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    float z[16];
-                    wsilu16<R>(acc[2 * np + hh], z, tab);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sums[0][g4]),
+                                                                 __float_as_uint(sums[1][g4]), false, false);
+                out[2 * g4] = to_half(__uint_as_float(sw[0]));
+                out[2 * g4 + 1] = to_half(__uint_as_float(sw[1]));
+            }
+        }
+    };
+    // 3 deep slabs of one ffn.0 channel pair (first channel `ch0`), with the epilogue of the previous
+    // pair (-> out) spread over the 24 k-slices when `with_prev`
+    auto ffn0_pair = [&](int slot0, int ch0, int next_shape_after, bool with_prev, half8& out) {
+        bias_tile(cur[0], lb0, ch0);
+        bias_tile(cur[1], lb0, ch0 + 32);
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        sum[hh][g4] = ((z[4 * g4] + z[4 * g4 + 1]) + z[4 * g4 + 2]) + z[4 * g4 + 3];
+        for (int k3 = 0; k3 < 3; ++k3) {
+            step_deep(g, (slot0 + k3) % NS, k3 == 2 ? next_shape_after : DEEP, [&](int s) { return bf[8 * k3 + s]; }, cur,
+                      [&](int s) {
+                          const int slot24 = 8 * k3 + s;            // one piece every third slice, combine last
+                          if (with_prev && slot24 % 3 == 1) ffn0_piece(slot24 / 3, out);
+                          if (with_prev && slot24 == 23) ffn0_piece(8, out);
+                      });
+            ++g;
+        }
+        park(cur);
+    };
+    // 3 wide slabs of ffn.2 for the 64 channels of t in tt[0..3]; optionally carries an ffn.0 epilogue
+    auto ffn2_group = [&](int slot0, const half8 (&tt)[4], int next_shape_after, bool with_prev, half8& out) {
+#pragma unroll
+        for (int nc = 0; nc < 3; ++nc) {
+            step_wide(g, (slot0 + nc) % NS, nc == 2 ? next_shape_after : WIDE, [&](int s) { return tt[s]; },
+                      *reinterpret_cast<float16v(*)[4]>(&acc2[4 * nc]),
+                      [&](int s) {
+                          const int slot12 = 4 * nc + s;
+                          if (with_prev && slot12 < 8) ffn0_piece(slot12, out);
+                          if (with_prev && slot12 == 8) ffn0_piece(8, out);
+                      });
+            ++g;
+        }
+    };
+    auto finish_prev = [&](half8& out) {       // epilogue of the parked pair, not overlapped
+#pragma unroll
+        for (int q = 0; q <= 8; ++q) ffn0_piece(q, out);
+    };
+
+    stamp();                                         // 2: y1 epilogue done
+    // super-chunk 0: pairs 0..3 (slots (18 + 3 j) % 5)
+    ffn0_pair((G_A + 0) % NS, 0, DEEP, false, t3[0]);
+    ffn0_pair((G_A + 3) % NS, 64, DEEP, true, t3[0]);
+    ffn0_pair((G_A + 6) % NS, 128, DEEP, true, t3[1]);
+    ffn0_pair((G_A + 9) % NS, 192, DEEP, true, t3[2]);
+    // super-chunks 1..5: pair 0 (finishes t3[3] of the previous one) | ffn.2 of the previous one (carries
+    // pair 0's epilogue) | pairs 1..3
+    for (int sc = 1; sc < 6; ++sc) {
+        stamp();                                     // 3..7: super-chunk sc starts
+        ffn0_pair(0, sc * 256, WIDE, true, t3[3]);
+        ffn2_group(3, t3, DEEP, true, t3n);
+        t3[0] = t3n;
+        ffn0_pair(6 % NS, sc * 256 + 64, DEEP, false, t3n);
+        ffn0_pair(9 % NS, sc * 256 + 128, DEEP, true, t3[1]);
+        ffn0_pair(12 % NS, sc * 256 + 192, sc == 5 ? WIDE : DEEP, true, t3[2]);
+    }
+    stamp();                                         // 8: walk done
+    finish_prev(t3[3]);
+    ffn2_group(G_A + G_B0 + G_LOOP, t3, DEEP, false, t3n);
+    stamp();                                         // 9: last ffn.2 group done
+
+    // ================================================================ ffn.2 epilogue: y
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        half8 o8[8];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int i = 8 * c + 2 * nt + pr;           // k-slice index = channels 16 i + 8 hi ..
+                float v[8];
+                runs_of(acc2[4 * c + nt], pr, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(bf[i][e]);
+                if (p.shortcut) {
+                    const half8 r8 = *reinterpret_cast<const half8*>(xrow + 16 * i);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
+                }
+                if (p.q != nullptr) {
+                    const half8 q8 = *reinterpret_cast<const half8*>(lq + 16 * i + 8 * hi);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
                 }
                 half8 o;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[0][g4]),
-                                                                     __float_as_uint(sum[1][g4]), false, false);
-                    o[2 * g4] = to_half(__uint_as_float(sw[0]));
-                    o[2 * g4 + 1] = to_half(__uint_as_float(sw[1]));
+                for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                if (p.q2 != nullptr) {
+                    const half8 q8 = *reinterpret_cast<const half8*>(lq2 + 16 * i + 8 * hi);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
                 }
-                t3[2 * h + np] = o;
+                bf[i] = o;
+                o8[2 * nt + pr] = o;
             }
-        }
-#pragma unroll
-        for (int nc = 0; nc < 3; ++nc) {
-            float16v a4[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) a4[nt] = acc2[4 * nc + nt];
-            slab_step(g, (G_A + 12 + nc) % NS, [&](int s) { return t3[s]; }, a4);
-            ++g;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc2[4 * nc + nt] = a4[nt];
-        }
+        flush(o8, std::integral_constant<int, 128>{}, p.y, p.ldy, 128 * c);
     }
 
-    // ================================================================ ffn.2 epilogue: y
-    {
-        const half_t* xrow = p.x + static_cast<size_t>(mc) * p.ldx + 8 * hi;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            half8 o8[8];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int i = 8 * c + 2 * nt + pr;           // k-slice index = channels 16 i + 8 hi ..
-                    float v[8];
-                    runs_of(acc2[4 * c + nt], pr, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(bf[i][e]);
-                    if (p.shortcut) {
-                        const half8 r8 = *reinterpret_cast<const half8*>(xrow + 16 * i);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
-                    }
-                    if (p.q != nullptr) {
-                        const half8 q8 = *reinterpret_cast<const half8*>(p.q + 16 * i + 8 * hi);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
-                    }
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-                    if (p.q2 != nullptr) {
-                        const half8 q8 = *reinterpret_cast<const half8*>(p.q2 + 16 * i + 8 * hi);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
-                    }
-                    bf[i] = o;
-                    o8[2 * nt + pr] = o;
-                }
-            flush128(o8, p.y, p.ldy, 128 * c);
-        }
-    }
-
+    stamp();                                         // 10: y written
     // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')
     if (p.w1n != nullptr) {
-        for (int c = 0; c < 3; ++c) {
-            float16v acc[4];
-            bias_init(acc, p.b1n, 128 * c);
+        half8 o4[4];
+        // epilogue run r (tile r>>1, half r&1) of the pair in `prev`; r == 4: the pair's 64 channels go out
+        auto dc0_piece = [&](int r, int first) {
+            if (r < 4) {
+                // run r = (tile r>>1, half r&1): parked units 2 (r&1) and 2 (r&1) + 1 of that tile, half-waves paired
+                const float4v lo4 = parked((r >> 1) * 4 + 2 * (r & 1));
+                const float4v hi4 = parked((r >> 1) * 4 + 2 * (r & 1) + 1);
+                float v[8];
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                slab_step(g, (G_A + G_B + 6 * c + ks) % NS, [&](int s) { return bf[ks * 4 + s]; }, acc);
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo4[e]), __float_as_uint(hi4[e]), false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                wsilu_n<8, R>(v, tab);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                o4[r] = o;
+            } else if (r == 4) {
+                flush(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first);
+            }
+        };
+        auto dc0_pair = [&](int j, bool with_prev) {
+            bias_tile(cur[0], lb1n, 64 * j);
+            bias_tile(cur[1], lb1n, 64 * j + 32);
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+                step_deep(g, g % NS, DEEP, [&](int s) { return bf[8 * k3 + s]; }, cur,
+                          [&](int s) {
+                              const int slot24 = 8 * k3 + s;
+                              if (with_prev && slot24 % 5 == 2 && slot24 < 20) dc0_piece(slot24 / 5, 64 * (j - 1));
+                              if (with_prev && slot24 == 22) dc0_piece(4, 64 * (j - 1));
+                          });
                 ++g;
             }
-            half8 o8[8];
+            park(cur);
+        };
+        dc0_pair(0, false);
+        for (int j = 1; j < 6; ++j) dc0_pair(j, true);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    float v[8];
-                    runs_of(acc[nt], pr, v);
-                    wsilu8<R>(v, tab);
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-                    o8[2 * nt + pr] = o;
-                }
-            flush128(o8, p.t1n, p.ldt1, 128 * c);
-        }
+        for (int r = 0; r <= 4; ++r) dc0_piece(r, 64 * 5);
     }
+    // the prefetches behind the last slab are still on their way into this workgroup's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();                                         // 11: end
 }
 
+long long* g_core_timeline = nullptr;
+
 }  // namespace
+
+void dcb_core_timeline_buffer(long long* device_buffer)
+{
+    g_core_timeline = device_buffer;
+}
 
 bool dcb_core_supported(int c, int cdc, int cffn)
 {
@@ -422,13 +686,21 @@ void dcb_core(const DcbCoreDesc& d, hipStream_t stream)
     p.q = d.q; p.q2 = d.q2; p.w1n = d.w1n; p.b1n = d.b1n; p.t1n = d.t1n; p.ldt1 = d.ldt1;
     p.wsilu = wsilu_table_device();
     p.y = d.y; p.ldy = d.ldy; p.M = d.pixels; p.shortcut = d.shortcut ? 1 : 0;
+    p.timeline = g_core_timeline;
     static std::once_flag once;
     std::call_once(once, [] {
-        hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(dcb_core_kernel),
+        hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(dcb_core_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES),
+                  "hipFuncSetAttribute(dcb_core)");
+        hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(dcb_core_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES),
                   "hipFuncSetAttribute(dcb_core)");
     });
-    hipLaunchKernelGGL(dcb_core_kernel, dim3((d.pixels + BM - 1) / BM), dim3(NTHREADS), SMEM_BYTES, stream, p);
+    if (p.timeline != nullptr) {
+        hipLaunchKernelGGL(dcb_core_kernel<true>, dim3((d.pixels + BM - 1) / BM), dim3(NTHREADS), SMEM_BYTES, stream, p);
+    } else {
+        hipLaunchKernelGGL(dcb_core_kernel<false>, dim3((d.pixels + BM - 1) / BM), dim3(NTHREADS), SMEM_BYTES, stream, p);
+    }
     hip_check(hipGetLastError(), "dcb_core launch");
 }
 

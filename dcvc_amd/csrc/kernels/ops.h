@@ -74,6 +74,7 @@ struct DcbCoreDesc {
     bool shortcut = false;
 };
 bool dcb_core_supported(int c, int cdc, int cffn);
+void dcb_core_timeline_buffer(long long* device_buffer);     // tuning aid: [workgroups][64] shader-clock stamps
 void dcb_core(const DcbCoreDesc& d, hipStream_t stream);
 
 struct ConvKxKDesc {

@@ -153,6 +153,19 @@ class CompressionModel(nn.Module):
         }
         self.proxy = None
 
+    def set_cdf_info(self, z_cdf, z_len, y_cdf, y_len):
+        """Installs precomputed tables instead of update()'s. Encoder and decoder must use the SAME
+        tables, and update() evaluates softplus / tanh / sigmoid / erf on whatever device and CPU it
+        runs on: measured here, an Intel and an AMD host build tables that differ in a few entries
+        from identical parameters (the reference has the same property, it builds them on the GPU,
+        entropy_models.py:113-217). Ship the tables with the stream's model when hosts differ."""
+        i32 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+        self._cdf = {
+            "gaussian_encoder.quantized_cdf": i32(y_cdf), "gaussian_encoder.cdf_length": i32(y_len),
+            "bit_estimator_z.quantized_cdf": i32(z_cdf), "bit_estimator_z.cdf_length": i32(z_len),
+        }
+        self.proxy = None
+
     def get_cdf_info(self):
         c = self._cdf
         return (c["bit_estimator_z.quantized_cdf"], c["bit_estimator_z.cdf_length"],

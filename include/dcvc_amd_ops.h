@@ -112,6 +112,8 @@ int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H, int W, void* y16,
 /* Tuning aid (no reference counterpart): device buffer of [blocks][16] int64 shader-clock stamps
  * written by wave 0 of every workgroup of the following contraction launches; NULL = off. */
 int dcvc_gemm_timeline_buffer(void* device_buffer);
+/* the same for dcvc_dcb_core: [workgroups][64] stamps (entry, then one per weight slab) */
+int dcvc_dcb_core_timeline_buffer(void* device_buffer);
 
 /* def_elementwise.h: round_z_cuda / int8_to_dtype_cuda */
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream);

@@ -50,9 +50,26 @@ def state_dict_digest(model):
             a = a.astype(np.float16)
         h.update(k.encode())
         h.update(np.ascontiguousarray(a).tobytes())
-    for t in model.get_cdf_info():
-        h.update(np.ascontiguousarray(t.numpy() if hasattr(t, "numpy") else t).tobytes())
     return h.hexdigest()
+
+
+CDF_OUT = os.path.join(HERE, "fullsize_cdf.npz")
+
+
+def save_cdf_tables():
+    """The entropy tables the digests were made with (update() is host-dependent in the last place:
+    an Intel and an AMD host quantise a few frequencies differently); int32 -> uint16/uint8, compressed."""
+    from codec_util import dmc_ht_model, dmc_ld_model, dmci_model
+    out = {}
+    for kind, m in (("dmci", dmci_model(skip_thres=0.15)), ("ld", dmc_ld_model(skip_thres=0.15)),
+                    ("hts", dmc_ht_model("hts", skip_thres=0.15)), ("htl", dmc_ht_model("htl", skip_thres=0.15))):
+        z_cdf, z_len, y_cdf, y_len = [np.asarray(t) for t in m.get_cdf_info()]
+        assert z_cdf.max() <= 65536 and z_len.max() < 256
+        out[kind + "_z_cdf"] = z_cdf.astype(np.uint32)
+        out[kind + "_z_len"] = z_len.astype(np.uint8)
+        out[kind + "_y_cdf"] = y_cdf.astype(np.uint32)
+        out[kind + "_y_len"] = y_len.astype(np.uint8)
+    np.savez_compressed(CDF_OUT, **out)
 
 
 def padded(x):
@@ -143,6 +160,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
+    save_cdf_tables()
     done = {}
     if os.path.exists(OUT):
         with open(OUT) as f:

@@ -483,7 +483,8 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
 @pytest.mark.parametrize("P,shortcut,quant,q2,nxt,inplace", [
     (128, False, False, False, False, False),       # one workgroup
     (300, False, False, False, True, True),         # ragged last workgroup, in place, next dc.0 fused
-    (1000, True, True, False, False, False),        # block shortcut + fused quant (not in place)
+    (1000, True, False, False, False, False),       # block shortcut (not in place)
+    (777, False, True, False, True, True),          # fused quant (the inter encoders' conv2 form)
     (2040, False, False, True, True, False),        # scale on the rounded output + next dc.0
     (32640, False, False, False, True, True),       # 1080p P8 grid (255 workgroups), the chain configuration
     (32640, True, False, True, False, False),
