@@ -29,7 +29,7 @@ COMMON = [
     # SLP packing of scalar fp32 math into v_pk_* costs more v_mov / s_nop than it saves on gfx950
     "-fno-slp-vectorize",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-]
+] + os.environ.get("DCVC_EXTRA_DEFS", "").split()      # tuning experiments: extra -D flags
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-munsafe-fp-atomics"]
 
 

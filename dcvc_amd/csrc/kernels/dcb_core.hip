@@ -192,8 +192,10 @@ dcb_core_kernel(const CoreParams p)
         ltbl[tid] = reinterpret_cast<unsigned long long>(base) | static_cast<unsigned long long>(shape);
     }
     struct Pending { const half_t* src; int jstride; unsigned dst; };
+    unsigned long long next_entry = 0;      // table entry of the slab the NEXT step prefetches: read one step early
     auto plan_slab = [&](int g, int slot) {
-        const unsigned long long e = ltbl[g];
+        const unsigned long long e = next_entry;
+        next_entry = ltbl[g + 1];
         const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(e));
         const unsigned hi32 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(e >> 32));
         const bool deep = (lo & 1u) != 0;
@@ -319,6 +321,7 @@ dcb_core_kernel(const CoreParams p)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     stamp();                                         // 0: first slab there
+    next_entry = ltbl[NS - 1];
     if (warm == 0x9e3779b9u && p.M < 0) p.y[0] = static_cast<half_t>(0);     // never true: keeps the warm-up loads alive
     // One slab = 16 MFMAs per wave. The barrier at the top of step g certifies slab g+1 (every wave
     // waited for its own share) and frees the slot of slab g-1 for the prefetch of slab g+4; slab g
@@ -327,53 +330,112 @@ dcb_core_kernel(const CoreParams p)
     // step, but the 16 registers that then live across every step boundary push hipcc into spilling
     // B fragments inside the walk - measured: 176 spilled registers with, 14 outside the loops without.)
     // piece(s): VALU work (the epilogue of an EARLIER accumulator set) placed behind the MFMAs of k-slice s.
-    auto step_top = [&](int g, int slot) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    // `extra`: register-destination loads issued within the last three steps (they sit between the
+    // stream's own operations in the in-order queue and must not be mistaken for them)
+    auto step_top = [&](int g, int slot, auto extra) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS + decltype(extra)::value) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         return plan_slab(g + NS - 1, (slot + NS - 1) % NS);
     };
-    auto step_wide = [&](int g, int slot, int /*next_shape*/, auto&& bfrag, float16v (&acc)[4], auto&& piece) {
-        const Pending nx = step_top(g, slot);
+    // A lone wave per SIMD issues in order: four MFMAs in a row block the wave for three pipe times
+    // and everything else is issued afterwards with the matrix pipe idle (measured: 190 instead of
+    // 128 cycles per 4-MFMA slice). The instruction groups below ask the scheduler for
+    // MFMA | a few LDS reads | a few VALU | MFMA | ... inside each region (a region ends at the
+    // LDS-DMA asm, which nothing crosses).
+#ifdef DCB_CORE_SGB
+#define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SGB_DSRD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define SGB_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+#else
+#define SGB_MFMA(n)
+#define SGB_DSRD(n)
+#define SGB_VALU(n)
+#endif
+    // head[]: the first fragments of a step, read at the END of the step before (the slab was certified
+    // by that step's barrier): tiles 0..3 of k-slice 0 (wide) / tiles 0,1 of k-slices 0,1 (deep).
+    // next_tag: shape of the following slab, or NONE = the following step reads its own head
+    // (have_head = false there); both are compile-time at every call site.
+    half8 head[4];
+    auto load_head = [&](auto shape_tag, const char* ws) {
+        if constexpr (decltype(shape_tag)::value == WIDE) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) head[nt] = frag_w(ws, nt, 0);
+        } else {
+            head[0] = frag_d(ws, 0, 0); head[1] = frag_d(ws, 1, 0);
+            head[2] = frag_d(ws, 0, 1); head[3] = frag_d(ws, 1, 1);
+        }
+    };
+    auto step_wide = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[4], auto&& piece,
+                         auto vtag, auto extra) {
+        constexpr int valu_per_mfma = decltype(vtag)::value;
+        const Pending nx = step_top(g, slot, extra);
         const char* ws = smem + slot * SLAB;
+        if constexpr (!decltype(have_head)::value) load_head(std::integral_constant<int, WIDE>{}, ws);
         half8 wf[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[0][nt] = frag_w(ws, nt, 0);
+        for (int nt = 0; nt < 4; ++nt) wf[0][nt] = head[nt];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < 3) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) wf[(s + 1) & 1][nt] = frag_w(ws, nt, s + 1);
+            } else if constexpr (decltype(next_tag)::value >= 0) {
+                load_head(next_tag, smem + ((slot + 1) % NS) * SLAB);
             }
             const half8 b = bfrag(s);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], b, acc[nt], 0, 0, 0);
-            issue_part(nx, s);
             piece(s);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                SGB_MFMA(1);
+                SGB_DSRD(2);
+                if constexpr (valu_per_mfma > 0) SGB_VALU(valu_per_mfma);
+            }
+            issue_part(nx, s);
             SLICE_FENCE();
         }
     };
-    auto step_deep = [&](int g, int slot, int /*next_shape*/, auto&& bfrag, float16v (&acc)[2], auto&& piece) {
-        const Pending nx = step_top(g, slot);
+    auto step_deep = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[2], auto&& piece,
+                         auto vtag, auto extra) {
+        constexpr int valu_per_mfma = decltype(vtag)::value;
+        const Pending nx = step_top(g, slot, extra);
         const char* ws = smem + slot * SLAB;
+        if constexpr (!decltype(have_head)::value) load_head(std::integral_constant<int, DEEP>{}, ws);
         half8 wf[3][2];
-        wf[0][0] = frag_d(ws, 0, 0); wf[0][1] = frag_d(ws, 1, 0); wf[1][0] = frag_d(ws, 0, 1); wf[1][1] = frag_d(ws, 1, 1);
+        wf[0][0] = head[0]; wf[0][1] = head[1]; wf[1][0] = head[2]; wf[1][1] = head[3];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             if (s + 2 < 8) {
                 wf[(s + 2) % 3][0] = frag_d(ws, 0, s + 2);
                 wf[(s + 2) % 3][1] = frag_d(ws, 1, s + 2);
+            } else if (s == 6) {
+                if constexpr (decltype(next_tag)::value >= 0) load_head(next_tag, smem + ((slot + 1) % NS) * SLAB);
             }
             const half8 b = bfrag(s);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][0], b, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][1], b, acc[1], 0, 0, 0);
-            if ((s & 1) == 0) issue_part(nx, s >> 1);
             piece(s);
-            SLICE_FENCE();
+            if (s & 1) {                 // one region = two k-slices = 4 MFMAs, closed by the LDS-DMA piece
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    SGB_MFMA(1);
+                    SGB_DSRD(2);
+                    if constexpr (valu_per_mfma > 0) SGB_VALU(valu_per_mfma);
+                }
+                issue_part(nx, s >> 1);
+                SLICE_FENCE();
+            }
         }
     };
+    using TagW = std::integral_constant<int, WIDE>;
+    using TagD = std::integral_constant<int, DEEP>;
+    using TagNone = std::integral_constant<int, -1>;
+    using Yes = std::true_type;
+    using No = std::false_type;
     auto no_piece = [](int) {};
 
     // accumulator tile (32 channels from `first`) initialised with the bias:
@@ -439,8 +501,18 @@ dcb_core_kernel(const CoreParams p)
     for (int ks = 0; ks < 6; ++ks) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            step_wide(g, (3 * ks + c) % NS, (ks == 5 && c == 2) ? DEEP : WIDE, [&](int s) { return bf[ks * 4 + s]; },
-                      *reinterpret_cast<float16v(*)[4]>(&acc2[4 * c]), no_piece);
+            // the 8 loads of a third of x go out behind the k-steps 2, 3, 4: for the three steps that
+            // follow each of them they are younger than the slab the barrier certifies
+            auto run = [&](auto have, auto next, auto extra) {
+                step_wide(g, (3 * ks + c) % NS, have, next, [&](int s) { return bf[ks * 4 + s]; },
+                          *reinterpret_cast<float16v(*)[4]>(&acc2[4 * c]), no_piece, std::integral_constant<int, 0>{}, extra);
+            };
+            using X0 = std::integral_constant<int, 0>;
+            using X8 = std::integral_constant<int, 8>;
+            if (ks == 0 && c == 0) run(No{}, TagW{}, X0{});
+            else if (ks == 5 && c == 2) run(Yes{}, TagD{}, X8{});
+            else if (ks >= 3) run(Yes{}, TagW{}, X8{});
+            else run(Yes{}, TagW{}, X0{});
             ++g;
         }
         if (ks >= 2 && ks <= 4) {
@@ -511,32 +583,42 @@ dcb_core_kernel(const CoreParams p)
     };
     // 3 deep slabs of one ffn.0 channel pair (first channel `ch0`), with the epilogue of the previous
     // pair (-> out) spread over the 24 k-slices when `with_prev`
-    auto ffn0_pair = [&](int slot0, int ch0, int next_shape_after, bool with_prev, half8& out) {
+    auto ffn0_pair = [&](int slot0, int ch0, auto have_head, auto next_after, bool with_prev, half8& out) {
         bias_tile(cur[0], lb0, ch0);
         bias_tile(cur[1], lb0, ch0 + 32);
 #pragma unroll
         for (int k3 = 0; k3 < 3; ++k3) {
-            step_deep(g, (slot0 + k3) % NS, k3 == 2 ? next_shape_after : DEEP, [&](int s) { return bf[8 * k3 + s]; }, cur,
-                      [&](int s) {
-                          const int slot24 = 8 * k3 + s;            // one piece every third slice, combine last
-                          if (with_prev && slot24 % 3 == 1) ffn0_piece(slot24 / 3, out);
-                          if (with_prev && slot24 == 23) ffn0_piece(8, out);
-                      });
+            auto body = [&](auto have, auto next) {
+                step_deep(g, (slot0 + k3) % NS, have, next, [&](int s) { return bf[8 * k3 + s]; }, cur,
+                          [&](int s) {
+                              const int slot24 = 8 * k3 + s;            // one piece every third slice, combine last
+                              if (with_prev && slot24 % 3 == 1) ffn0_piece(slot24 / 3, out);
+                              if (with_prev && slot24 == 23) ffn0_piece(8, out);
+                          }, std::integral_constant<int, 10>{}, std::integral_constant<int, 0>{});
+            };
+            if (k3 == 0) body(have_head, TagD{});
+            else if (k3 == 1) body(Yes{}, TagD{});
+            else body(Yes{}, next_after);
             ++g;
         }
         park(cur);
     };
     // 3 wide slabs of ffn.2 for the 64 channels of t in tt[0..3]; optionally carries an ffn.0 epilogue
-    auto ffn2_group = [&](int slot0, const half8 (&tt)[4], int next_shape_after, bool with_prev, half8& out) {
+    auto ffn2_group = [&](int slot0, const half8 (&tt)[4], auto have_head, auto next_after, bool with_prev, half8& out) {
 #pragma unroll
         for (int nc = 0; nc < 3; ++nc) {
-            step_wide(g, (slot0 + nc) % NS, nc == 2 ? next_shape_after : WIDE, [&](int s) { return tt[s]; },
-                      *reinterpret_cast<float16v(*)[4]>(&acc2[4 * nc]),
-                      [&](int s) {
-                          const int slot12 = 4 * nc + s;
-                          if (with_prev && slot12 < 8) ffn0_piece(slot12, out);
-                          if (with_prev && slot12 == 8) ffn0_piece(8, out);
-                      });
+            auto body = [&](auto have, auto next) {
+                step_wide(g, (slot0 + nc) % NS, have, next, [&](int s) { return tt[s]; },
+                          *reinterpret_cast<float16v(*)[4]>(&acc2[4 * nc]),
+                          [&](int s) {
+                              const int slot12 = 4 * nc + s;
+                              if (with_prev && slot12 < 8) ffn0_piece(slot12, out);
+                              if (with_prev && slot12 == 8) ffn0_piece(8, out);
+                          }, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
+            };
+            if (nc == 0) body(have_head, TagW{});
+            else if (nc == 1) body(Yes{}, TagW{});
+            else body(Yes{}, next_after);
             ++g;
         }
     };
@@ -547,24 +629,25 @@ dcb_core_kernel(const CoreParams p)
 
     stamp();                                         // 2: y1 epilogue done
     // super-chunk 0: pairs 0..3 (slots (18 + 3 j) % 5)
-    ffn0_pair((G_A + 0) % NS, 0, DEEP, false, t3[0]);
-    ffn0_pair((G_A + 3) % NS, 64, DEEP, true, t3[0]);
-    ffn0_pair((G_A + 6) % NS, 128, DEEP, true, t3[1]);
-    ffn0_pair((G_A + 9) % NS, 192, DEEP, true, t3[2]);
+    ffn0_pair((G_A + 0) % NS, 0, Yes{}, TagD{}, false, t3[0]);
+    ffn0_pair((G_A + 3) % NS, 64, Yes{}, TagD{}, true, t3[0]);
+    ffn0_pair((G_A + 6) % NS, 128, Yes{}, TagD{}, true, t3[1]);
+    ffn0_pair((G_A + 9) % NS, 192, Yes{}, TagNone{}, true, t3[2]);
     // super-chunks 1..5: pair 0 (finishes t3[3] of the previous one) | ffn.2 of the previous one (carries
-    // pair 0's epilogue) | pairs 1..3
+    // pair 0's epilogue) | pairs 1..3. (The step behind the last pair differs between the iterations and
+    // the exit, so the first step of an iteration reads its own head.)
     for (int sc = 1; sc < 6; ++sc) {
         stamp();                                     // 3..7: super-chunk sc starts
-        ffn0_pair(0, sc * 256, WIDE, true, t3[3]);
-        ffn2_group(3, t3, DEEP, true, t3n);
+        ffn0_pair(0, sc * 256, No{}, TagW{}, true, t3[3]);
+        ffn2_group(3, t3, Yes{}, TagD{}, true, t3n);
         t3[0] = t3n;
-        ffn0_pair(6 % NS, sc * 256 + 64, DEEP, false, t3n);
-        ffn0_pair(9 % NS, sc * 256 + 128, DEEP, true, t3[1]);
-        ffn0_pair(12 % NS, sc * 256 + 192, sc == 5 ? WIDE : DEEP, true, t3[2]);
+        ffn0_pair(6 % NS, sc * 256 + 64, Yes{}, TagD{}, false, t3n);
+        ffn0_pair(9 % NS, sc * 256 + 128, Yes{}, TagD{}, true, t3[1]);
+        ffn0_pair(12 % NS, sc * 256 + 192, Yes{}, TagNone{}, true, t3[2]);
     }
     stamp();                                         // 8: walk done
     finish_prev(t3[3]);
-    ffn2_group(G_A + G_B0 + G_LOOP, t3, DEEP, false, t3n);
+    ffn2_group(G_A + G_B0 + G_LOOP, t3, No{}, TagNone{}, false, t3n);
     stamp();                                         // 9: last ffn.2 group done
 
     // ================================================================ ffn.2 epilogue: y
@@ -630,23 +713,26 @@ dcb_core_kernel(const CoreParams p)
                 flush(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first);
             }
         };
-        auto dc0_pair = [&](int j, bool with_prev) {
+        auto dc0_pair = [&](int j, auto have_head, bool with_prev) {
             bias_tile(cur[0], lb1n, 64 * j);
             bias_tile(cur[1], lb1n, 64 * j + 32);
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
-                step_deep(g, g % NS, DEEP, [&](int s) { return bf[8 * k3 + s]; }, cur,
-                          [&](int s) {
-                              const int slot24 = 8 * k3 + s;
-                              if (with_prev && slot24 % 5 == 2 && slot24 < 20) dc0_piece(slot24 / 5, 64 * (j - 1));
-                              if (with_prev && slot24 == 22) dc0_piece(4, 64 * (j - 1));
-                          });
+                auto body = [&](auto have) {
+                    step_deep(g, g % NS, have, TagD{}, [&](int s) { return bf[8 * k3 + s]; }, cur,
+                              [&](int s) {
+                                  const int slot24 = 8 * k3 + s;
+                                  if (with_prev && slot24 % 5 == 2 && slot24 < 20) dc0_piece(slot24 / 5, 64 * (j - 1));
+                                  if (with_prev && slot24 == 22) dc0_piece(4, 64 * (j - 1));
+                              }, std::integral_constant<int, 10>{}, std::integral_constant<int, 0>{});
+                };
+                if (k3 == 0) body(have_head); else body(Yes{});
                 ++g;
             }
             park(cur);
         };
-        dc0_pair(0, false);
-        for (int j = 1; j < 6; ++j) dc0_pair(j, true);
+        dc0_pair(0, No{}, false);
+        for (int j = 1; j < 6; ++j) dc0_pair(j, Yes{}, true);
 #pragma unroll
         for (int r = 0; r <= 4; ++r) dc0_piece(r, 64 * 5);
     }

@@ -76,6 +76,5 @@ def main():
         print("   %-40s %7.0f cycles  (p90 %7.0f)" % (names[i + 1] if i + 1 < len(names) else "?", np.median(d[:, i]), np.percentile(d[:, i], 90)))
     print("   total %.0f cycles" % np.median(s[:, 11] - s[:, 0]))
 
-
 if __name__ == "__main__":
     main()
