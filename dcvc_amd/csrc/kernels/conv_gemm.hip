@@ -627,6 +627,25 @@ void gemm_profile_enable(bool on)
     profile().on = on;
 }
 
+bool gemm_profile_slot(const GemmLaunchInfo& info, hipEvent_t* start, hipEvent_t* stop)
+{
+    GemmProfile& pf = profile();
+    if (!pf.on) return false;
+    std::lock_guard<std::mutex> lk(pf.mu);
+    if (pf.used == pf.events.size()) {
+        hipEvent_t a, b;
+        hip_check(hipEventCreate(&a), "hipEventCreate");
+        hip_check(hipEventCreate(&b), "hipEventCreate");
+        pf.events.emplace_back(a, b);
+        pf.info.push_back(GemmLaunchInfo{});
+    }
+    pf.info[pf.used] = info;
+    *start = pf.events[pf.used].first;
+    *stop = pf.events[pf.used].second;
+    ++pf.used;
+    return true;
+}
+
 void gemm_profile_reset()
 {
     profile().used = 0;

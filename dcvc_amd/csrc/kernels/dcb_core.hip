@@ -29,6 +29,8 @@
 #include "ops.h"
 #include "wsilu_table.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 #include <mutex>
 #include <stdexcept>
@@ -782,7 +784,13 @@ void dcb_core(const DcbCoreDesc& d, hipStream_t stream)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES),
                   "hipFuncSetAttribute(dcb_core)");
     });
-    if (p.timeline != nullptr) {
+    hipEvent_t ev0, ev1;
+    const int kflop = (d.w1n != nullptr ? 7 : 6) * C;            // 2 * pixels * C * kflop = FLOPs of the launch
+    if (p.timeline == nullptr &&
+        gemm_profile_slot(GemmLaunchInfo{d.pixels, C, kflop, static_cast<int>(0x80000000u), 0.f}, &ev0, &ev1)) {
+        hipExtLaunchKernelGGL(dcb_core_kernel<false>, dim3((d.pixels + BM - 1) / BM), dim3(NTHREADS), SMEM_BYTES, stream,
+                              ev0, ev1, 0, p);
+    } else if (p.timeline != nullptr) {
         hipLaunchKernelGGL(dcb_core_kernel<true>, dim3((d.pixels + BM - 1) / BM), dim3(NTHREADS), SMEM_BYTES, stream, p);
     } else {
         hipLaunchKernelGGL(dcb_core_kernel<false>, dim3((d.pixels + BM - 1) / BM), dim3(NTHREADS), SMEM_BYTES, stream, p);

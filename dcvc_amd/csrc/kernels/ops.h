@@ -36,6 +36,10 @@ struct GemmLaunchInfo {
     float ms;
 };
 size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap);
+// Other contraction kernels (dcb_core.hip) register their launches in the same list: when profiling
+// is on, reserves a record and hands out the two events hipExtLaunchKernelGGL stamps; false = off.
+// info.K is chosen such that 2 * M * N * K is the launch's FLOP count; variant bit 31 marks dcb_core.
+bool gemm_profile_slot(const GemmLaunchInfo& info, hipEvent_t* start, hipEvent_t* stop);
 // Tuning aid: when non-null, wave 0 of every workgroup of the following contraction launches
 // writes up to 16 shader-clock stamps (kernel entry, prologue issued, start of k-steps 0..7, main
 // loop done, epilogue math done, stores issued) to buffer[block * 16 + i]. Null switches it off.

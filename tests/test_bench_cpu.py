@@ -1,7 +1,7 @@
-"""bench.py's control flow and JSON contract on a CPU box: the GPU pieces (codec, streams, kernel
-stamps) are replaced by stand-ins, everything else - argument handling, lane dealing, the timed
-region, the fields of the one JSON line the driver parses - is the real code."""
-import contextlib
+"""bench.py's control flow and JSON contract on a CPU box: the GPU pieces (codec, streams, events,
+kernel stamps) are replaced by stand-ins, everything else - argument handling, the timed region,
+the separate encode / decode timing pass, the other-workload runs, the fields of the one JSON line
+the driver parses - is the real code."""
 import json
 import sys
 import time
@@ -20,27 +20,53 @@ class _FakeStream:
         pass
 
 
+class _FakeEvent:
+    def __init__(self, *a, **k):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
 class _FakeNet:
     def get_padding_size(self, h, w, p):
         return (-w) % p, (-h) % p
 
 
 class _FakeWork:
-    frames, kind, graphs = 1, "intra", True
-    made = 0
+    kind, default_graphs = "intra", True
+    made = []
 
     def __init__(self, *a, **k):
-        type(self).made += 1
+        self.frames = 1
+        type(self).made.append(self)
         self.calls = []
 
-    def step(self, i, qp):
+    def prepare(self, i):
+        pass
+
+    def compress(self, i, qp):
         assert qp in bench.QPS
-        self.calls.append((i, qp))
+        self.calls.append(("c", i))
         time.sleep(0.001)
-        return 1000
+        return {"bit_stream": b"x" * 1000, "ec_parallel": 1}
+
+    def decompress(self, i, qp, enc):
+        self.calls.append(("d", i))
+        time.sleep(0.002)
 
     def set_use_graphs(self, on):
         pass
+
+
+class _FakeInter(_FakeWork):
+    def __init__(self, kind, *a, **k):
+        super().__init__()
+        self.kind = kind
+        self.frames = 1 if kind == "ld" else 8
 
 
 @pytest.fixture
@@ -49,42 +75,64 @@ def fake_gpu(monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     monkeypatch.setattr(torch.cuda, "Stream", _FakeStream)
+    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
     monkeypatch.setattr(torch.cuda, "set_stream", lambda s: None)
-    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
-    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _FakeStream())
     monkeypatch.setattr(torch.cuda, "synchronize", lambda d=None: None)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
     monkeypatch.setattr(__graft_entry__, "build", lambda: None)
     monkeypatch.setattr(bench, "build_model", lambda device: (_FakeNet(), _FakeNet()))
-    monkeypatch.setattr(bench, "_to_gpu", lambda net, device: net)
     monkeypatch.setattr(bench, "make_pictures", lambda n, rank, device: [None] * n)
     monkeypatch.setattr(bench, "IntraWorkload", _FakeWork)
+    monkeypatch.setattr(bench, "InterWorkload", _FakeInter)
     monkeypatch.setattr(bench, "roofline", lambda work: {"bound": "mfma", "achieved": 1.0, "peak": 2500.0,
                                                         "unit": "TFLOP/s", "frac": 0.0004, "traffic": None})
     monkeypatch.setattr(bench, "cpu_baseline", lambda net: {"value": 1e-3, "unit": "frames/s", "cores": 1,
                                                             "kind": "port", "sample": "stand-in"})
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DCVC_BENCH_LANES", "DCVC_BENCH_EAGER", "DCVC_BENCH_POOL1"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
-    _FakeWork.made = 0
+    _FakeWork.made = []
 
 
-@pytest.mark.parametrize("lanes", [None, 1, 3])
-def test_one_json_line_with_the_contract_fields(fake_gpu, monkeypatch, capsys, lanes):
-    argv = ["bench.py", "--steps", "7", "--warmup", "2"] + ([] if lanes is None else ["--lanes", str(lanes)])
-    monkeypatch.setattr(sys, "argv", argv)
+def _run(monkeypatch, capsys, argv):
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
     bench.main()
     lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_one_json_line_with_the_contract_fields(fake_gpu, monkeypatch, capsys):
+    d = _run(monkeypatch, capsys, ["--steps", "7", "--warmup", "2"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "encode_fps", "decode_fps",
+                "other_workloads"):
         assert key in d, key
-    n = lanes or 1
     assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f16"
-    assert d["config"]["lanes"] == n and d["config"]["pictures_per_step"] == n and "workload" in d["config"]
+    assert d["config"]["pictures_per_step"] == 1 and "workload" in d["config"] and "model" not in d["config"]
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
-    assert d["value"] == pytest.approx(n * 7 / (d["ms_per_step"] * 7 / 1e3), rel=1e-6)
+    assert d["value"] == pytest.approx(7 / (d["ms_per_step"] * 7 / 1e3), rel=1e-6)
     assert d["bytes_per_picture"] == 1000
-    assert _FakeWork.made == n
-    assert ("one_lane" in d) == (n > 1)
+    # compress takes 1 ms and decompress 2 ms in the stand-in: the two rates are measured separately
+    assert d["encode_fps"] > d["decode_fps"] > 0
+    assert 1.5 < d["encode_fps"] / d["decode_fps"] < 2.6
+    assert set(d["other_workloads"]) == {"ld", "hts", "htl"}
+    for kind, o in d["other_workloads"].items():
+        assert set(o) >= {"value", "encode_fps", "decode_fps", "ms_per_step"} and o["value"] > 0
+    assert d["other_workloads"]["hts"]["value"] > d["other_workloads"]["ld"]["value"]     # 8 pictures per call
+
+
+def test_timed_region_runs_exactly_k_steps(fake_gpu, monkeypatch, capsys):
+    d = _run(monkeypatch, capsys, ["--steps", "5", "--warmup", "3", "--no-extras", "--no-roofline", "--no-cpu-baseline"])
+    w = _FakeWork.made[0]
+    timed_and_warm = [c for c in w.calls if c[0] == "c" and c[1] < 8]
+    assert len(timed_and_warm) == 8                       # 3 warm-up + 5 timed, then the per-call timing pass
+    assert "roofline" not in d and "cpu_baseline" not in d and "other_workloads" not in d
+
+
+def test_inter_workload_line(fake_gpu, monkeypatch, capsys):
+    d = _run(monkeypatch, capsys, ["--steps", "4", "--warmup", "1", "--workload", "hts", "--no-extras"])
+    assert d["config"]["pictures_per_step"] == 8 and "HT-S" in d["metric"]
+    assert d["value"] == pytest.approx(8 * 4 / (d["ms_per_step"] * 4 / 1e3), rel=1e-6)
+    assert "cpu_baseline" not in d                        # the CPU baseline belongs to the headline workload

@@ -103,43 +103,6 @@ def test_corrupt_stream_does_not_crash():
     torch.cuda.synchronize()
     assert torch.isfinite(d["x_hat"].float()).all()
 
-
-def test_lanes_code_the_same_bytes():
-    """dcvc_amd.lanes: three lanes (own codec objects, stream and host thread each) coding 12
-    pictures concurrently give, picture by picture, the bytes and reconstructions of one codec
-    coding them one after the other."""
-    import copy
-    from dcvc_amd.lanes import LanePool
-    m, g = _gpu_net(0.15)
-    hw = (144, 208)
-    pr, pb = g.get_padding_size(hw[0], hw[1], 16)
-    units = [(to_device_input(picture(*hw, index=i)), (7 * i) % 64) for i in range(12)]
-
-    def code(net, unit):
-        x, qp = unit
-        enc = net.compress(x, qp, pb, pr)
-        dec = net.decompress(enc["bit_stream"], {"height": hw[0], "width": hw[1]}, qp, enc["ec_parallel"])
-        return enc["bit_stream"], enc["x_hat"].clone(), dec["x_hat"].clone()
-
-    want = [code(g, u) for u in units]
-    torch.cuda.synchronize()
-
-    def lane(k):
-        n = copy.deepcopy(m).half().cuda()
-        n.proxy = None
-        return n
-
-    pool = LanePool(3, lane, torch.device("cuda", torch.cuda.current_device()))
-    pool.warm(lambda k, net: code(net, units[0]))
-    got = pool.map(code, units)
-    torch.cuda.synchronize()
-    assert len({id(s._ensure_proxy()) for s in pool.states}) == 3
-    for i, (w, r) in enumerate(zip(want, got)):
-        assert r[0] == w[0], "picture %d: bytes differ" % i
-        assert torch.equal(r[1], w[1]) and torch.equal(r[2], w[2]), "picture %d: reconstruction differs" % i
-        assert torch.equal(r[1], r[2])
-
-
 def test_null_stream_consumer_sees_finished_results():
     """compress() returns as soon as the bit stream is complete - the reconstruction tail is still
     running on the codec's stream. A consumer queued on torch's default (legacy null) stream right

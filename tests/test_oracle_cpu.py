@@ -260,6 +260,44 @@ def test_vector_and_scalar_contractions_are_identical(kind):
         lib.orc_avx512(1)
 
 
+def test_torch_restatement_of_the_reference_cpu_path(golden):
+    """oracle/torch_graph.py (what bench.py times as the reference's CPU path on the GPU box, where
+    /root/reference does not exist) against x_hat made by the reference's own
+    DMCI.forward_one_frame (tests/golden/make_dmci_golden.py), and live against the reference module
+    when the tree is present. fp32 graph vs fp32 graph: equal up to summation order."""
+    import torch
+    from dcvc_amd import arch, synthetic
+    from oracle import torch_graph
+    sd = synthetic.synthetic_state_dict(arch.dmci_spec(), 0)
+    for i, qp in enumerate((32, 5, 60)):
+        x = torch.from_numpy(golden["x_%d" % i].astype(np.float32)).permute(2, 0, 1).unsqueeze(0)
+        got = torch_graph.forward_one_frame(sd, x, qp)[0].permute(1, 2, 0).numpy()
+        want = golden["xhat_%d" % i].astype(np.float32)
+        # a flipped rounding decision moves a latent by one step: bound the damage, demand near-identity
+        psnr = 10 * np.log10(1.0 / np.mean((got - want) ** 2))
+        assert psnr > 55, (i, psnr)
+    if os.path.isdir("/root/reference/src/models"):
+        import sys
+        from oracle import build_oracle, rans as orc
+        try:
+            build_oracle.build_ref()
+            sys.modules.setdefault("MLCodec_extensions_cpp", orc.load_ref())
+            sys.path.insert(0, "/root/reference")
+            from src.models.image_model import DMCI
+        except Exception as e:
+            pytest.skip("reference module does not import here: %s" % e)
+        finally:
+            if "/root/reference" in sys.path:
+                sys.path.remove("/root/reference")
+        net = DMCI().eval()
+        net.load_state_dict(sd, strict=True)
+        x = torch.rand((1, 3, 64, 128), generator=torch.Generator().manual_seed(3)) - 0.5
+        with torch.no_grad():
+            want = net.forward_one_frame(x, torch.tensor([20]), recon_only=True)
+        got = torch_graph.forward_one_frame(sd, x, 20)
+        assert torch.allclose(got, want, atol=2e-5), float((got - want).abs().max())
+
+
 def test_c_abi_exports_every_declared_symbol():
     from tools import check_abi
     assert len(check_abi.declared_symbols()) >= 40
