@@ -30,6 +30,7 @@ The JSON line (rank 0) carries, besides the driver contract:
                             oracle's compress + decompress; N = 1 only, bounded samples
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -219,8 +220,12 @@ def cpu_baseline(cpu_net):
     cores = os.cpu_count() or 1
     sd = cpu_net.state_dict()
     full = HEIGHT * WIDTH
-    # all cores: one padded 1080p picture (1088x1920); one thread: a 256x256 crop, scaled by area
-    t_all = torch_graph.time_forward(sd, 1088, 1920, 32, cores)
+    # thread count: the fastest of {all, 64, 32, 16} on a 512x512 crop (oversubscribing a 2-socket host with one
+    # small convolution per op is slower than one thread), then one padded 1080p picture (1088x1920) with it;
+    # one thread: a 256x256 crop, scaled by area
+    tried = {t: torch_graph.time_forward(sd, 512, 512, 32, t) for t in sorted({min(cores, c) for c in (cores, 64, 32, 16)})}
+    best = min(tried, key=tried.get)
+    t_all = torch_graph.time_forward(sd, 1088, 1920, 32, best)
     t_one = torch_graph.time_forward(sd, 256, 256, 32, 1) * (1088 * 1920) / (256 * 256)
     h = w = 160
     y, uv = synthetic.synthetic_frame_yuv420(h, w, 0, 0)
@@ -231,10 +236,11 @@ def cpu_baseline(cpu_net):
     o.decompress(r["bit_stream"], 32, h, w, r["ec_parallel"])
     t_orc = (time.time() - t0) * full / (h * w)
     return {
-        "value": 1.0 / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
+        "value": 1.0 / t_all, "unit": "frames/s", "cores": best, "kind": "port",
         "sample": "fp32 PyTorch graph of the reference's CPU-runnable path (DMCI.forward_one_frame, image_model.py:150-171, "
                   "restated in oracle/torch_graph.py: encoder + priors + decoder of one 1088x1920 picture, no entropy coding) "
-                  "on %d threads: %.2f s per picture" % (cores, t_all),
+                  "on %d of %d hardware threads (fastest of %s on a 512x512 crop): %.2f s per picture"
+                  % (best, cores, {t: round(v, 2) for t, v in tried.items()}, t_all),
         "one_thread": {"value": 1.0 / t_one, "unit": "frames/s", "cores": 1,
                        "sample": "the same graph on 1 thread (the reference harness pins 1, common.py:270): one 256x256 crop, "
                                  "scaled by area to 1080p (%.1f s per picture)" % t_one},
@@ -330,7 +336,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
     import __graft_entry__
     if rank == 0:
-        __graft_entry__.build()
+        with contextlib.redirect_stdout(sys.stderr):     # stdout carries the ONE JSON line and nothing else
+            __graft_entry__.build()
     if dist is not None:
         dist.barrier()
 

@@ -37,7 +37,7 @@ def _sources():
     srcs = []
     for pat in ("*.cpp", "*.hip", "*/*.cpp", "*/*.hip"):
         srcs += glob.glob(os.path.join(CSRC, pat))
-    return sorted(s for s in srcs if os.sep + "_obj" not in s)
+    return sorted(s for s in srcs if os.sep + "_obj" not in s and os.sep + "cli" + os.sep not in s)
 
 
 def _headers():
@@ -87,8 +87,8 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = _sources()
     manifest = LIB + ".manifest"
-    digest = _digest(srcs + _headers())
-    if not force and os.path.exists(LIB) and os.path.exists(manifest):
+    digest = _digest(srcs + _headers() + [CLI_SRC])
+    if not force and os.path.exists(LIB) and os.path.exists(manifest) and os.path.exists(CLI_BIN):
         with open(manifest) as f:
             if f.read().strip() == digest:
                 return LIB
@@ -120,7 +120,26 @@ def build(force=False, verbose=False):
         raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
     with open(manifest, "w") as f:
         f.write(digest)
+    build_cli(verbose)
     return LIB
+
+
+CLI_SRC = os.path.join(CSRC, "cli", "dcvc_cli.hip")
+CLI_BIN = os.path.join(PKG, "bin", "dcvc")
+
+
+def build_cli(verbose=False):
+    """The standalone encoder / decoder (dcvc_amd/bin/dcvc): host code on top of the C ABI, linked
+    against libdcvc_amd.so next to it."""
+    os.makedirs(os.path.dirname(CLI_BIN), exist_ok=True)
+    cmd = [_hipcc()] + COMMON + ["-x", "hip"] + HIP_FLAGS + [CLI_SRC, "-x", "none", "-o", CLI_BIN, "-L", PKG, "-ldcvc_amd",
+                                                       "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed (dcvc tool):\n%s\n%s" % (res.stdout, res.stderr))
+    return CLI_BIN
 
 
 if __name__ == "__main__":

@@ -268,6 +268,32 @@ int dcvc_dmcht_import_state(dcvc_dmcht* c, const void* src, size_t bytes, int he
     return dcvc::guarded([&] { c->codec.import_state(src, bytes, height, width, static_cast<hipStream_t>(stream)); });
 }
 
+int dcvc_dmcht_set_recon_mask(dcvc_dmcht* c, unsigned mask)
+{
+    return dcvc::guarded([&] { c->codec.set_recon_mask(mask); });
+}
+
+int64_t dcvc_dmcht_export_feature(dcvc_dmcht* c, void* dst, size_t cap, void* stream)
+{
+    int64_t n = -1;
+    const int rc = dcvc::guarded([&] {
+        n = static_cast<int64_t>(c->codec.export_feature(dst, cap, static_cast<hipStream_t>(stream)));
+    });
+    return rc < 0 ? rc : n;
+}
+
+int dcvc_dmcht_import_feature(dcvc_dmcht* c, const void* src, size_t bytes, int height, int width, void* stream)
+{
+    return dcvc::guarded([&] { c->codec.import_feature(src, bytes, height, width, static_cast<hipStream_t>(stream)); });
+}
+
+int dcvc_dmcht_run_recon_heads(dcvc_dmcht* c, unsigned mask, void* x_hat, void* stream)
+{
+    return dcvc::guarded([&] {
+        c->codec.run_recon_heads(mask, static_cast<dcvc::half_t*>(x_hat), static_cast<hipStream_t>(stream));
+    });
+}
+
 int dcvc_dmcht_set_use_graphs(dcvc_dmcht* c, int on)
 {
     return dcvc::guarded([&] { c->codec.set_use_graphs(on != 0); });

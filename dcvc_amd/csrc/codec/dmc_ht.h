@@ -45,6 +45,20 @@ public:
     size_t export_state(void* dst, size_t cap, hipStream_t stream);
     void import_state(const void* src, size_t bytes, int height, int width, hipStream_t stream);
 
+    // Reconstruction-head fan-out (SURVEY 8e iii): the 8 picture heads depend only on feature_p
+    // (video_model_ht.py:252-275, dmc_hts_proxy.cpp:325-360), so after decompress() has produced it
+    // on the GPU that holds the stream's temporal state, other GPUs can run the heads.
+    //   set_recon_mask(m)        decompress() runs only the heads of the pictures in bit mask m
+    //                            (bit 7 = the last picture, whose head output is also the reset feature:
+    //                            it belongs to the GPU that keeps the state)
+    //   export_feature(dst)      feature_p as one dense [P8][512] fp16 device buffer (33.4 MB at 1080p)
+    //   import_feature(src,h,w)  the receiving side: installs it into a codec with the same parameters
+    //   run_recon_heads(m, out)  heads of mask m -> out + i * picture for every i in m
+    void set_recon_mask(unsigned mask);
+    size_t export_feature(void* dst, size_t cap, hipStream_t stream);
+    void import_feature(const void* src, size_t bytes, int height, int width, hipStream_t stream);
+    void run_recon_heads(unsigned mask, half_t* x_hat, hipStream_t stream);
+
 private:
     struct Geometry {
         int H8 = 0, W8 = 0, H16 = 0, W16 = 0, H16p = 0, W16p = 0, H32 = 0, W32 = 0, H64 = 0, W64 = 0;
@@ -132,6 +146,7 @@ private:
     bool m_enc_ready = false;          // memory and ctx are those of the next chunk to encode
     bool m_memory_has_value = false;
     bool m_has_feature_p = false;
+    unsigned m_recon_mask = 0xffu;     // pictures whose heads decompress() runs
 };
 
 }  // namespace dcvc

@@ -260,10 +260,14 @@ void DmcHtCodec::run_recon_head(half_t* x_hat, hipStream_t st)
     const View feature(m_CATM + kChM, kChM + kChD, kChD);
     const View rc(m_RC, kChD, kChD), rt(m_RT, kChRecon, kChRecon);
     const size_t picture = static_cast<size_t>(g.P8()) * 64 * 3;
+    bool trunk_done = false;       // HT-S: pictures 2j and 2j+1 share the trunk recon_head.conv1.j
     for (int i = 0; i < kFrames; ++i) {
+        if (i % 2 == 0) trunk_done = false;
+        if (!(m_recon_mask >> i & 1u)) continue;
         View trunk = feature;
         if (m_hts) {
-            if (i % 2 == 0) m_rh_common[i / 2].forward(feature, rc, g.H8, g.W8, m_s, st);
+            if (!trunk_done) m_rh_common[i / 2].forward(feature, rc, g.H8, g.W8, m_s, st);
+            trunk_done = true;
             trunk = rc;
         }
         m_rh[i].forward(trunk, rt, rt, g.H8, g.W8, m_s, st);
@@ -541,6 +545,59 @@ void DmcHtCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
     m_has_ref = true;
     m_memory_has_value = !reset;
     m_enc_ready = false;                   // ctx was advanced by this chunk; the encoder side must be re-seeded
+}
+
+// ------------------------------------------------------------------------------------ recon-head fan-out
+void DmcHtCodec::set_recon_mask(unsigned mask)
+{
+    mask &= 0xffu;
+    if (mask == m_recon_mask) return;
+    quiesce();
+    clear_graphs();              // the captured decode stages contain the head launches
+    m_recon_mask = mask;
+}
+
+size_t DmcHtCodec::export_feature(void* dst, size_t cap, hipStream_t user)
+{
+    if (!m_has_params || m_g.H8 == 0 || !m_has_feature_p) throw std::runtime_error("DMC-HT export_feature: no feature_p yet");
+    const Geometry& g = m_g;
+    const size_t bytes = static_cast<size_t>(g.P8()) * kChD * sizeof(half_t);
+    if (dst == nullptr) return bytes;
+    if (cap < bytes) throw std::invalid_argument("DMC-HT export_feature: destination too small");
+    hipStream_t st = enter(user);
+    // strided [P8][1024] view -> dense [P8][512]
+    replicate_pad(m_CATM + kChM, kChM + kChD, g.H8, g.W8, kChD, 0, 0, static_cast<half_t*>(dst), kChD, st);
+    leave(user);
+    return bytes;
+}
+
+void DmcHtCodec::import_feature(const void* src, size_t bytes, int height, int width, hipStream_t user)
+{
+    prepare(height, width);
+    const Geometry& g = m_g;
+    if (bytes != static_cast<size_t>(g.P8()) * kChD * sizeof(half_t)) {
+        throw std::invalid_argument("DMC-HT import_feature: size does not match the picture size");
+    }
+    hipStream_t st = enter(user);
+    replicate_pad(static_cast<const half_t*>(src), kChD, g.H8, g.W8, kChD, 0, 0, m_CATM + kChM, kChM + kChD, st);
+    leave(user);
+    m_has_feature_p = true;
+}
+
+void DmcHtCodec::run_recon_heads(unsigned mask, half_t* x_hat, hipStream_t user)
+{
+    if (!m_has_params || m_g.H8 == 0 || !m_has_feature_p) throw std::runtime_error("DMC-HT run_recon_heads: no feature_p");
+    hipStream_t st = enter(user);
+    const unsigned keep = m_recon_mask;
+    m_recon_mask = mask & 0xffu;
+    try {
+        run_recon_head(x_hat, st);           // eager: not part of a captured stage
+    } catch (...) {
+        m_recon_mask = keep;
+        throw;
+    }
+    m_recon_mask = keep;
+    leave(user);
 }
 
 // ------------------------------------------------------------------------------------ state hand-off

@@ -58,6 +58,10 @@ _HT = dict(
     use_graphs=_lib.fn("dcvc_dmcht_set_use_graphs", _ci, [_vp, _ci]),
     export_state=_lib.fn("dcvc_dmcht_export_state", ctypes.c_int64, [_vp, _vp, ctypes.c_size_t, _vp]),
     import_state=_lib.fn("dcvc_dmcht_import_state", _ci, [_vp, _vp, ctypes.c_size_t, _ci, _ci, _vp]),
+    set_recon_mask=_lib.fn("dcvc_dmcht_set_recon_mask", _ci, [_vp, ctypes.c_uint]),
+    export_feature=_lib.fn("dcvc_dmcht_export_feature", ctypes.c_int64, [_vp, _vp, ctypes.c_size_t, _vp]),
+    import_feature=_lib.fn("dcvc_dmcht_import_feature", _ci, [_vp, _vp, ctypes.c_size_t, _ci, _ci, _vp]),
+    run_recon_heads=_lib.fn("dcvc_dmcht_run_recon_heads", _ci, [_vp, ctypes.c_uint, _vp, _vp]),
     debug_read=_lib.fn("dcvc_dmcht_debug_read", ctypes.c_int64, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, _vp]),
 )
 
@@ -251,6 +255,36 @@ class _DMCHTProxy(_Proxy):
                                      int(width), int(entropy_coder_parallel),
                                      1 if reset_feature_memory else 0,
                                      ctypes.c_void_p(self._x_hat.data_ptr()), _stream_ptr()))
+        return [self._x_hat[i:i + 1] for i in range(self.FRAMES)]
+
+    # ---- reconstruction-head fan-out over several GPUs (not part of the reference surface; SURVEY 8e iii)
+    def set_recon_mask(self, mask):
+        """decompress() runs only the heads of the pictures in bit mask `mask` (the other entries of the
+        returned list are then not written)."""
+        _lib.check(_HT["set_recon_mask"](self._h, int(mask) & 0xFF))
+
+    def export_feature(self):
+        """feature_p of the last decompress() as a dense fp16 device tensor [P8, 512]"""
+        n = _lib.check(_HT["export_feature"](self._h, None, 0, _stream_ptr()))
+        t = torch.empty(int(n) // 2, dtype=torch.float16, device=torch.device("cuda", torch.cuda.current_device()))
+        _lib.check(_HT["export_feature"](self._h, ctypes.c_void_p(t.data_ptr()), int(n), _stream_ptr()))
+        return t
+
+    def import_feature(self, feature, height, width):
+        if not feature.is_cuda or not feature.is_contiguous() or feature.dtype != torch.float16:
+            raise ValueError("expected a contiguous fp16 CUDA tensor")
+        _lib.check(_HT["import_feature"](self._h, ctypes.c_void_p(feature.data_ptr()), feature.numel() * 2, int(height),
+                                         int(width), _stream_ptr()))
+
+    def run_recon_heads(self, mask, height, width):
+        """heads of the pictures in `mask` on the imported / own feature_p -> list of 8 x_hat (only those of
+        the mask are written)"""
+        device = torch.device("cuda", torch.cuda.current_device())
+        h16, w16 = (int(height) + 15) // 16 * 16, (int(width) + 15) // 16 * 16
+        if self._x_hat is None or tuple(self._x_hat.shape) != (self.FRAMES, 3, h16, w16) or self._x_hat.device != device:
+            self._x_hat = torch.empty((self.FRAMES, 3, h16, w16), dtype=torch.float16, device=device).contiguous(
+                memory_format=torch.channels_last)
+        _lib.check(_HT["run_recon_heads"](self._h, int(mask) & 0xFF, ctypes.c_void_p(self._x_hat.data_ptr()), _stream_ptr()))
         return [self._x_hat[i:i + 1] for i in range(self.FRAMES)]
 
 

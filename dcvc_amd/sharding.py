@@ -91,6 +91,60 @@ def code_sharded(n_units, code_unit, dist=None):
     return gather_units(local, dist)
 
 
+# ------------------------------------------------------------------ reconstruction-head fan-out (HT models)
+# The one place where a chunk of 8 pictures splits one-picture-per-GPU (SURVEY 8e iii): the 8 heads
+# of the hierarchical models depend only on feature_p (video_model_ht.py:252-275; 36 % of HT-S's
+# decode MACs, 22 % of HT-L's). Rank `src` owns the stream: it decodes (entropy decoding, priors,
+# decoder - everything that defines the bytes stays on one GPU), broadcasts feature_p (33.4 MB at
+# 1080p: one RCCL broadcast, on xGMI 7 point-to-point links), every rank runs its heads.
+def head_owner(picture, world):
+    """rank that reconstructs `picture` (0..7) of a chunk. Picture 7 stays with rank 0 (its head
+    output is the reset feature of the temporal state); with 2 or 4 ranks whole picture pairs stay
+    together (HT-S pairs share a trunk block)."""
+    if world <= 1:
+        return 0
+    if world in (2, 4):
+        return (3 - picture // 2) % world
+    return (7 - picture) % world
+
+
+def head_mask(rank, world):
+    return sum(1 << i for i in range(8) if head_owner(i, world) == rank)
+
+
+def decompress_fanout(proxy, bit_stream, qp, height, width, ec_parallel, reset, dist, src=0):
+    """One chunk of an HT stream decoded over all ranks of `dist`. `bit_stream` etc. are needed on
+    rank `src` only. Returns this rank's {picture index: x_hat tensor}."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mask = head_mask((rank - src) % world, world)
+    if rank == src:
+        proxy.set_recon_mask(mask)
+        out = proxy.decompress(bit_stream, qp, height, width, ec_parallel, reset)
+        feature = proxy.export_feature()
+    else:
+        h8, w8 = (height + 15) // 16 * 2, (width + 15) // 16 * 2
+        feature = torch.empty(h8 * w8 * 512, dtype=torch.float16, device=_device_for(dist))
+    if world > 1:
+        dist.broadcast(feature, src)
+    if rank != src:
+        proxy.import_feature(feature, height, width)
+        out = proxy.run_recon_heads(mask, height, width)
+    return {i: out[i] for i in range(8) if mask >> i & 1}
+
+
+def gather_pictures(mine, dist, dst=0):
+    """{picture: [1, 3, H, W] tensor} of every rank -> on rank `dst` the 8 pictures in display order."""
+    world = dist.get_world_size()
+    if world == 1:
+        return [mine[i] for i in range(8)]
+    any_t = next(iter(mine.values()))
+    buf = torch.zeros((8,) + tuple(any_t.shape[1:]), dtype=any_t.dtype, device=any_t.device)
+    for i, t in mine.items():
+        buf[i] = t[0]
+    dist.reduce(buf, dst, op=dist.ReduceOp.SUM)          # every picture is non-zero on exactly one rank
+    return [buf[i:i + 1] for i in range(8)] if dist.get_rank() == dst else None
+
+
 # ------------------------------------------------------------------ GOP hand-off between GPUs
 # Inside a GOP the coding order is strictly sequential, but WHERE the next picture is coded is free
 # as long as the temporal state travels with it: DMCLDProxy.export_state() packs it into one flat

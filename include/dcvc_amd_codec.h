@@ -19,6 +19,12 @@
 extern "C" {
 #endif
 
+/* message of the last failing call on this thread (every dcvc_* entry point reports errors through it) */
+#ifndef DCVC_LAST_ERROR_DECLARED
+#define DCVC_LAST_ERROR_DECLARED
+const char* dcvc_last_error(void);
+#endif
+
 typedef struct dcvc_dmci dcvc_dmci;
 
 /* tensor element types of dcvc_*_set_param */
@@ -132,6 +138,16 @@ int dcvc_dmcht_decompress(dcvc_dmcht* c, const uint8_t* bit_stream, size_t nbyte
 /* GOP hand-off between GPUs, as dcvc_dmcld_export_state / _import_state */
 int64_t dcvc_dmcht_export_state(dcvc_dmcht* c, void* dst, size_t cap, void* stream);
 int dcvc_dmcht_import_state(dcvc_dmcht* c, const void* src, size_t bytes, int height, int width, void* stream);
+/* Not part of the reference surface - reconstruction-head fan-out over several GPUs (SURVEY 8e iii;
+ * video_model_ht.py:252-275: the 8 picture heads depend only on feature_p). The GPU that holds the
+ * stream decodes with dcvc_dmcht_set_recon_mask(own pictures), exports feature_p (dense device
+ * buffer [P8][512] fp16; dst == NULL returns the size), the others import it and run their heads:
+ * x_hat + i * picture is written for every picture i of `mask` (bit i). Bit 7 (the last picture)
+ * must stay with the GPU that keeps the temporal state: its head output is the reset feature. */
+int dcvc_dmcht_set_recon_mask(dcvc_dmcht* c, unsigned mask);
+int64_t dcvc_dmcht_export_feature(dcvc_dmcht* c, void* dst, size_t cap, void* stream);
+int dcvc_dmcht_import_feature(dcvc_dmcht* c, const void* src, size_t bytes, int height, int width, void* stream);
+int dcvc_dmcht_run_recon_heads(dcvc_dmcht* c, unsigned mask, void* x_hat, void* stream);
 int dcvc_dmcht_set_use_graphs(dcvc_dmcht* c, int on);
 /* Test hook ("y", "y_hat", "common", "z_i8", "memory", "feature_p", "ctx", "feature_i", "symbols",
  * "totals"). */

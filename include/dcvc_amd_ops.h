@@ -17,6 +17,12 @@
 extern "C" {
 #endif
 
+/* message of the last failing call on this thread (every dcvc_* entry point reports errors through it) */
+#ifndef DCVC_LAST_ERROR_DECLARED
+#define DCVC_LAST_ERROR_DECLARED
+const char* dcvc_last_error(void);
+#endif
+
 /* flags for dcvc_conv1x1 */
 #define DCVC_CONV_WSILU      1   /* y = wsilu(acc + bias)                     (conv1x1_bias_wsilu)            */
 #define DCVC_CONV_CHUNK_ADD  2   /* sum of 4 adjacent output channels         (conv1x1_bias_wsilu_chunk_add)  */

@@ -17,6 +17,12 @@
 extern "C" {
 #endif
 
+/* message of the last failing call on this thread (every dcvc_* entry point reports errors through it) */
+#ifndef DCVC_LAST_ERROR_DECLARED
+#define DCVC_LAST_ERROR_DECLARED
+const char* dcvc_last_error(void);
+#endif
+
 typedef struct dcvc_rans_encoder dcvc_rans_encoder;
 typedef struct dcvc_rans_decoder dcvc_rans_decoder;
 

@@ -25,6 +25,12 @@
 extern "C" {
 #endif
 
+/* message of the last failing call on this thread (every dcvc_* entry point reports errors through it) */
+#ifndef DCVC_LAST_ERROR_DECLARED
+#define DCVC_LAST_ERROR_DECLARED
+const char* dcvc_last_error(void);
+#endif
+
 #define DCVC_NAL_SPS 0
 #define DCVC_NAL_I 1
 #define DCVC_NAL_P 2

@@ -1,0 +1,160 @@
+"""The standalone encoder / decoder (dcvc_amd/bin/dcvc) end to end on a real MI355X:
+a YUV420 file -> .bin (reference container) -> reconstruction file + log, against the SAME sequence
+driven through the Python plugin surface the way test_video.py:166-399 does it (models + stream
+container mirror + picture I/O kernels). Byte-identical stream, byte-identical reconstruction file,
+same PSNR / bpp log."""
+import ctypes
+import io
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from codec_util import dmc_ht_model, dmc_ld_model, dmci_model
+from dcvc_amd import _lib, export_weights, stream_helper as sh, synthetic
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "dcvc_amd", "bin", "dcvc")
+vp, ci = ctypes.c_void_p, ctypes.c_int
+
+
+def _gpu(m):
+    import copy
+    g = copy.deepcopy(m).half().cuda()
+    g.proxy = None
+    return g
+
+
+def _write_yuv(path, H, W, n):
+    frames = []
+    with open(path, "wb") as f:
+        for i in range(n):
+            y, uv = synthetic.synthetic_frame_yuv420(H, W, index=i, seed=3)
+            f.write(y.tobytes())
+            f.write(uv.tobytes())
+            frames.append((y, uv))
+    return frames
+
+
+def _planes(x_hat, H, W):
+    fn = _lib.fn("dcvc_x_to_yuv420", ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp])
+    xh = x_hat[0].permute(1, 2, 0).contiguous()
+    y16 = torch.empty((H, W), dtype=torch.float16, device="cuda")
+    uv16 = torch.empty((2, H // 2, W // 2), dtype=torch.float16, device="cuda")
+    y8 = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+    uv8 = torch.empty((2, H // 2, W // 2), dtype=torch.uint8, device="cuda")
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(fn(vp(xh.data_ptr()), xh.shape[1], H, W, vp(y16.data_ptr()), vp(uv16.data_ptr()), vp(y8.data_ptr()),
+                  vp(uv8.data_ptr()), s))
+    torch.cuda.synchronize()
+    return y16.cpu().numpy(), uv16.cpu().numpy(), y8.cpu().numpy(), uv8.cpu().numpy()
+
+
+def _psnr(a, b):
+    mse = np.mean(np.square(a.astype(np.float64) - b.astype(np.float64)))
+    return min(10 * np.log10(255.0 * 255.0 / mse), 99.9) if mse > 1e-10 else 99.9
+
+
+def _python_reference(frames, H, W, i_model, p_model, delay, qp_i, qp_p, reset_interval):
+    """test_video.py:204-399 on the plugin surface -> (stream bytes, reconstruction bytes, psnr list, bits list)"""
+    i_enc, i_dec = _gpu(i_model), _gpu(i_model)
+    p_enc = p_dec = None
+    if p_model is not None:
+        p_enc, p_dec = _gpu(p_model), _gpu(p_model)
+    pr, pb = i_enc.get_padding_size(H, W, 16)
+    out = io.BytesIO()
+    helper = sh.SPSHelper()
+
+    def x_of(idx_list):
+        xs = [synthetic.yuv420_to_x(*frames[i]).half().cuda() for i in idx_list]
+        return torch.cat(xs, dim=1).contiguous(memory_format=torch.channels_last)
+
+    n, idx = len(frames), 0
+    while idx < n:
+        intra = idx == 0 or p_model is None
+        want = 1 if intra else min(delay, n - idx)
+        ids = list(range(idx, idx + want))
+        while not intra and len(ids) < delay:
+            ids.append(ids[-1])
+        x = x_of(ids)
+        if intra:
+            qp, reset = qp_i, 0
+            enc = i_enc.compress(x, qp, pb, pr)
+            if p_enc is not None:
+                p_enc.add_ref_feature_from_frame(enc["x_hat"])
+        else:
+            qp = qp_p
+            reset = 1 if (reset_interval > 0 and (idx + delay) % reset_interval == 1) else 0
+            enc = p_enc.compress(x, qp, reset, pb, pr)
+        sps_id, new = helper.get_sps_id({"sps_id": -1, "height": H, "width": W})
+        if new:
+            sh.write_sps(out, {"sps_id": sps_id, "height": H, "width": W})
+        sh.write_ip(out, intra, sps_id, qp, enc["ec_parallel"], reset, enc["bit_stream"])
+        idx += want
+    data = out.getvalue()
+    # decode
+    f = io.BytesIO(data)
+    helper = sh.SPSHelper()
+    rec, psnr, decoded = b"", [], 0
+    while decoded < n:
+        h = sh.read_header(f)
+        while h["nal_type"] == sh.NalType.NAL_SPS:
+            helper.add_sps_by_id(sh.read_sps_remaining(f, h["sps_id"]))
+            h = sh.read_header(f)
+        sps = helper.get_sps_by_id(h["sps_id"])
+        qp, ec, reset, payload = sh.read_ip_remaining(f)
+        if h["nal_type"] == sh.NalType.NAL_I:
+            xs = [i_dec.decompress(payload, sps, qp, ec)["x_hat"]]
+            if p_dec is not None:
+                p_dec.add_ref_feature_from_frame(xs[0], apply_feature_adaptor=False)
+        else:
+            r = p_dec.decompress(payload, sps, qp, ec, reset)["x_hat"]
+            xs = r if isinstance(r, (list, tuple)) else [r]
+        for x_hat in xs:
+            if decoded >= n:
+                break
+            y16, uv16, y8, uv8 = _planes(x_hat, H, W)
+            rec += y8.tobytes() + uv8.tobytes()
+            y, uv = frames[decoded]
+            py, pu, pv = _psnr(y, y16), _psnr(uv[0], uv16[0]), _psnr(uv[1], uv16[1])
+            psnr.append((6 * py + pu + pv) / 8)
+            decoded += 1
+    return data, rec, psnr
+
+
+@pytest.mark.parametrize("inter,n", [(None, 3), ("ld", 6), ("hts", 11)])
+def test_encode_decode_files_equal_the_plugin_path(tmp_path, inter, n):
+    assert os.path.exists(TOOL), "dcvc_amd/bin/dcvc is built by python -m dcvc_amd.build"
+    H, W, qp_i, qp_p, reset_interval = 96, 128, 30, 36, 4
+    frames = _write_yuv(str(tmp_path / "in.yuv"), H, W, n)
+    mi = dmci_model(skip_thres=0.15)
+    mp = None if inter is None else dmc_ld_model(skip_thres=0.15) if inter == "ld" else dmc_ht_model(inter, skip_thres=0.15)
+    export_weights.write_dcvw(str(tmp_path / "i.dcvw"), "dmci", mi, 0.15)
+    args = ["--intra", str(tmp_path / "i.dcvw")]
+    if mp is not None:
+        export_weights.write_dcvw(str(tmp_path / "p.dcvw"), inter, mp, 0.15)
+        args += ["--inter", str(tmp_path / "p.dcvw")]
+    run = lambda a: subprocess.run([TOOL] + a, check=True, capture_output=True, text=True, timeout=600)
+    run(["encode"] + args + ["-i", str(tmp_path / "in.yuv"), "-W", str(W), "-H", str(H), "--qp-i", str(qp_i), "--qp-p", str(qp_p),
+                             "--reset-interval", str(reset_interval), "-o", str(tmp_path / "out.bin")])
+    r = run(["decode"] + args + ["-i", str(tmp_path / "out.bin"), "-o", str(tmp_path / "rec.yuv"), "--ref", str(tmp_path / "in.yuv"),
+                                 "--json", str(tmp_path / "log.json"), "-n", str(n)])
+    print(r.stdout)
+    delay = 1 if inter in (None, "ld") else 8
+    want_bin, want_rec, want_psnr = _python_reference(frames, H, W, mi, mp, delay, qp_i, qp_p, reset_interval)
+    got_bin = (tmp_path / "out.bin").read_bytes()
+    assert got_bin == want_bin, "the tool's stream differs from the plugin path's"
+    assert (tmp_path / "rec.yuv").read_bytes() == want_rec, "reconstruction file differs"
+    log = json.loads((tmp_path / "log.json").read_text())
+    n_i = n if inter is None else 1
+    assert log["i_frame_num"] == n_i and log["p_frame_num"] == n - n_i
+    assert log["ave_all_frame_psnr"] == pytest.approx(float(np.mean(want_psnr)), abs=1e-6)
+    assert log["ave_all_frame_bpp"] == pytest.approx(8.0 * len(want_bin) / (n * H * W), rel=1e-9)
+    # the log is what the BD-rate tool reads
+    from dcvc_amd import bd_rate
+    assert bd_rate.curves({"seq": {"q": log}})["seq"][0][0] == log["ave_all_frame_bpp"]

@@ -2,6 +2,7 @@
 through the reference's plugin surface (inference_extensions_cuda.DMCHTSProxy / DMCHTLProxy over
 the C ABI): bit-exact against the CPU oracle - rANS bytes, temporal state, all 8 reconstructions."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -170,3 +171,97 @@ def test_gop_hand_off_continues_bit_exactly():
     assert r2["bit_stream"] == r1["bit_stream"] and torch.equal(d2, d1)
     with pytest.raises(Exception, match="model structure"):
         _gpu_net(dmc_ht_model("htl", skip_thres=0.15))._ensure_proxy().import_state(enc.proxy.export_state(), hw[0], hw[1])
+
+
+@pytest.mark.parametrize("structure", ["hts", "htl"])
+def test_recon_head_fan_out_equals_one_gpu(structure):
+    """the owner of the stream decodes with its own head mask and exports feature_p,
+    a second codec object (standing in for another GPU) imports it and runs the remaining heads: the
+    8 pictures equal a plain decompress() bit for bit, for every split sharding.head_mask produces,
+    and the owner's temporal state carries on (the next chunk decodes identically)."""
+    from dcvc_amd import sharding
+    m = dmc_ht_model(structure, skip_thres=0.15)
+    hw = (96, 160)
+    sps = {"height": hw[0], "width": hw[1]}
+    ref = to_device_input(_padded(picture(*hw, index=0)))
+    enc, plain = _gpu_net(m), _gpu_net(m)
+    enc.add_ref_feature_from_frame(ref)
+    plain.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+    pb, pr = _pads(enc, *hw)
+    streams, want = [], []
+    for i, (qp, reset) in enumerate([(20, 0), (44, 1), (30, 0)]):
+        r = enc.compress(to_device_input(chunk(hw[0], hw[1], 1 + 8 * i)), qp, reset, pb, pr)
+        d = plain.decompress(r["bit_stream"], sps, qp, r["ec_parallel"], reset)["x_hat"]
+        torch.cuda.synchronize()
+        streams.append((r, qp, reset))
+        want.append([t.clone() for t in d])
+    for world in (2, 4, 8):
+        owner = _gpu_net(m)
+        owner.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+        helpers = [_gpu_net(m) for _ in range(world - 1)]
+        po = owner._ensure_proxy()
+        po.set_recon_mask(sharding.head_mask(0, world))
+        for c, (r, qp, reset) in enumerate(streams):
+            out = po.decompress(np.frombuffer(r["bit_stream"], dtype=np.uint8), qp, hw[0], hw[1], r["ec_parallel"], reset)
+            feature = po.export_feature()
+            got = {i: out[i].clone() for i in range(8) if sharding.head_owner(i, world) == 0}
+            for k, h in enumerate(helpers):
+                ph = h._ensure_proxy()
+                ph.import_feature(feature, hw[0], hw[1])
+                o = ph.run_recon_heads(sharding.head_mask(k + 1, world), hw[0], hw[1])
+                torch.cuda.synchronize()
+                got.update({i: o[i].clone() for i in range(8) if sharding.head_owner(i, world) == k + 1})
+            torch.cuda.synchronize()
+            assert sorted(got) == list(range(8))
+            for i in range(8):
+                assert torch.equal(got[i], want[c][i]), (world, c, i)
+
+
+def _fanout_rank(rank, world, port, structure, out_path):
+    import pickle
+    import torch.distributed as dist
+    from dcvc_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        m = dmc_ht_model(structure, skip_thres=0.15)
+        hw = (96, 160)
+        ref = to_device_input(_padded(picture(*hw, index=0)))
+        dec = _gpu_net(m)
+        r = None
+        if rank == 0:
+            enc = _gpu_net(m)
+            enc.add_ref_feature_from_frame(ref)
+            pb, pr = _pads(enc, *hw)
+            r = enc.compress(to_device_input(chunk(hw[0], hw[1], 1)), 28, 0, pb, pr)
+            dec.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+        p = dec._ensure_proxy()
+        mine = sharding.decompress_fanout(p, None if r is None else np.frombuffer(r["bit_stream"], dtype=np.uint8), 28,
+                                          hw[0], hw[1], 0 if r is None else r["ec_parallel"], False, dist)
+        pics = sharding.gather_pictures(mine, dist)
+        if rank == 0:
+            plain = _gpu_net(m)
+            plain.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+            want = plain.decompress(r["bit_stream"], {"height": hw[0], "width": hw[1]}, 28, r["ec_parallel"], 0)["x_hat"]
+            torch.cuda.synchronize()
+            ok = all(torch.equal(a, b) for a, b in zip(pics, want))
+            with open(out_path, "wb") as f:
+                pickle.dump(ok, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL broadcast of feature_p over xGMI)")
+def test_recon_head_fan_out_over_rccl(tmp_path):
+    import pickle
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "ok.pkl")
+    mp.spawn(_fanout_rank, args=(2, port, "hts", out), nprocs=2, join=True)
+    with open(out, "rb") as f:
+        assert pickle.load(f) is True

@@ -109,3 +109,77 @@ def test_gop_state_hand_off_between_two_ranks(tmp_path):
         n, size, data = pickle.load(f)
     want = torch.arange(100001, dtype=torch.int64).to(torch.uint8).numpy().tobytes()
     assert n == 100001 and size == (1080, 1920) and data == want
+
+
+# ------------------------------------------------------------------ recon-head fan-out (HT models)
+def test_head_masks_partition_the_chunk():
+    for world in (1, 2, 3, 4, 5, 8):
+        masks = [sharding.head_mask(r, world) for r in range(world)]
+        assert sum(masks) == 0xFF and all(a & b == 0 for i, a in enumerate(masks) for b in masks[i + 1:])
+        assert masks[0] & 0x80, "the last picture (reset feature) stays with the rank that owns the stream"
+    # 2 and 4 ranks keep the picture pairs that share a trunk block together
+    assert all(sharding.head_owner(2 * j, w) == sharding.head_owner(2 * j + 1, w) for w in (2, 4) for j in range(4))
+
+
+class _FakeHT:
+    """Stands in for DMCHTSProxy on the CPU: feature_p is a function of the bytes, picture i a function of
+    feature_p - enough to check who computes what and that rank 0 ends up with all 8 pictures."""
+    H8, W8 = 4, 6
+
+    def __init__(self):
+        self.mask, self.feature, self.decoded = 0xFF, None, 0
+
+    def set_recon_mask(self, mask):
+        self.mask = mask
+
+    def _heads(self, mask):
+        f = self.feature.float().reshape(self.H8 * self.W8, 512)
+        return [(f[:, :3].t().reshape(1, 3, self.H8, self.W8) * (i + 1)).half() if mask >> i & 1 else None for i in range(8)]
+
+    def decompress(self, bit_stream, qp, height, width, ec, reset):
+        self.decoded += 1
+        g = torch.Generator().manual_seed(len(bit_stream) + qp)
+        self.feature = torch.randn(self.H8 * self.W8 * 512, generator=g).half()
+        return self._heads(self.mask)
+
+    def export_feature(self):
+        return self.feature.clone()
+
+    def import_feature(self, feature, height, width):
+        self.feature = feature.clone()
+
+    def run_recon_heads(self, mask, height, width):
+        return self._heads(mask)
+
+
+def _fanout_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = _FakeHT()
+        mine = sharding.decompress_fanout(p, b"x" * 77 if rank == 0 else None, 30, 32, 48, 1, False, dist)
+        assert set(mine) == {i for i in range(8) if sharding.head_owner(i, world) == rank}
+        assert p.decoded == (1 if rank == 0 else 0), "only the owner of the stream touches the bytes"
+        pics = sharding.gather_pictures(mine, dist)
+        if rank == 0:
+            with open(out_path, "wb") as f:
+                pickle.dump([t.numpy().tobytes() for t in pics], f)
+        else:
+            assert pics is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_recon_head_fan_out_over_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "pics.pkl")
+    mp.spawn(_fanout_worker, args=(2, port, out), nprocs=2, join=True)
+    with open(out, "rb") as f:
+        got = pickle.load(f)
+    ref = _FakeHT()
+    want = [t.numpy().tobytes() for t in ref.decompress(b"x" * 77, 30, 32, 48, 1, False)]
+    assert got == want
