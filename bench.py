@@ -61,6 +61,9 @@ def parse_args():
     p.add_argument("--workload", default="intra", choices=tuple(NAMES),
                    help="intra = the headline configuration (BASELINE.json configs[1]); ld / hts / htl = configs[2]")
     p.add_argument("--frames", type=int, default=5, help="distinct synthetic pictures per rank")
+    p.add_argument("--fanout", action="store_true",
+                   help="hts / htl with --gpus N > 1: ONE stream, the 8 reconstruction heads of a chunk spread over the ranks "
+                        "(feature_p broadcast over RCCL; strong scaling) instead of N independent streams")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the short runs of the other three workloads")
@@ -162,6 +165,38 @@ class InterWorkload:
     def set_use_graphs(self, on):
         for g in (self.enc, self.dec):
             g._ensure_proxy().set_use_graphs(on)
+
+
+class FanoutWorkload(InterWorkload):
+    """ONE hierarchical stream decoded over all ranks. Rank 0 owns the stream (encoder and the
+    decoder's entropy / prior / decoder stages, temporal state); after its decode it broadcasts feature_p over
+    RCCL and every rank reconstructs its share of the 8 pictures (dcvc_amd/sharding.py decompress_fanout).
+    Strong scaling: the work of a step does not grow with the number of GPUs."""
+
+    def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r, dist):
+        super().__init__(kind, device, pics, gpu_intra, pad_b, pad_r)
+        self.dist, self.rank = dist, dist.get_rank()
+        if self.rank != 0:
+            self.enc = None
+
+    def prepare(self, i):
+        if self.rank == 0:
+            super().prepare(i)
+
+    def compress(self, i, qp):
+        if self.rank != 0:
+            return {"bit_stream": b"", "ec_parallel": 0}
+        return super().compress(i, qp)
+
+    def decompress(self, i, qp, enc):
+        from dcvc_amd import sharding
+        return sharding.decompress_fanout(self.dec._ensure_proxy(), np.frombuffer(enc["bit_stream"], dtype=np.uint8), qp,
+                                          HEIGHT, WIDTH, enc["ec_parallel"], bool(self._reset(i)), self.dist)
+
+    def set_use_graphs(self, on):
+        for g in (self.enc, self.dec):
+            if g is not None:
+                g._ensure_proxy().set_use_graphs(on)
 
 
 def run_steps(work, first, n):
@@ -350,7 +385,15 @@ def main():
             return IntraWorkload(gpu_net, pics, pad_b, pad_r)
         return InterWorkload(kind, device, pics, gpu_net, pad_b, pad_r)
 
-    work = make_work(args.workload)
+    fanout = args.fanout and world > 1
+    if args.fanout and args.workload not in ("hts", "htl"):
+        raise SystemExit("--fanout needs --workload hts or htl (the models with 8 reconstruction heads per call)")
+    work = FanoutWorkload(args.workload, device, pics, gpu_net, pad_b, pad_r, dist) if fanout else make_work(args.workload)
+    # independent streams: rank r codes the steps shard_range() gives it out of world * steps (weak scaling,
+    # no data-path collective); fan-out: every rank takes part in every step
+    from dcvc_amd import sharding
+    mine = range(args.steps) if fanout else sharding.shard_range(world * args.steps, rank, world)
+    assert len(mine) == args.steps
 
     def sync():
         if dist is not None:
@@ -360,7 +403,7 @@ def main():
     run_steps(work, 0, args.warmup)
     sync()
     t0 = time.perf_counter()
-    nbytes = run_steps(work, args.warmup, args.steps)
+    nbytes = run_steps(work, args.warmup + mine.start, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -368,18 +411,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0:
+    if fanout:       # every rank takes part in the per-call timing loop (the broadcast is a collective)
         te, td = call_times(work, args.warmup + args.steps, min(args.steps, 32) + DROP_CALLS)
-        fps = world * args.steps * work.frames / elapsed
+    if rank == 0:
+        if not fanout:
+            te, td = call_times(work, args.warmup + args.steps, min(args.steps, 32) + DROP_CALLS)
+        fps = (1 if fanout else world) * args.steps * work.frames / elapsed
         out = {
             "metric": "1080p YUV420 %s encode+decode pictures per second (%s, real rANS bit streams, q_index in {0,16,32,48,63})"
                       % ("intra" if args.workload == "intra" else "inter", NAMES[args.workload]),
             "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": "strong" if fanout else "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the reference architecture)",
-            "config": {"workload": "%s 1080p YUV420 on 1xMI355X per rank, q_index cycling {0,16,32,48,63}, skip_thres 0.15, "
-                                   "one step = compress + decompress of %d picture(s)" % (NAMES[args.workload], work.frames),
+            "config": {"workload": ("%s 1080p YUV420, ONE stream over all ranks (rank 0 codes, feature_p broadcast, reconstruction "
+                                    "heads fanned out), " if fanout else "%s 1080p YUV420 on 1xMI355X per rank, ") % NAMES[args.workload]
+                                   + "q_index cycling {0,16,32,48,63}, skip_thres 0.15, one step = compress + decompress of %d "
+                                     "picture(s)" % work.frames,
+                       "sharding": "recon-head fan-out" if fanout else "independent streams (sharding.shard_range)",
                        "pictures_per_step": work.frames, "resolution": "%dx%d" % (WIDTH, HEIGHT)},
             "encode_fps": work.frames / te, "decode_fps": work.frames / td,
             "avg_frame_encoding_time_ms": 1e3 * te / work.frames, "avg_frame_decoding_time_ms": 1e3 * td / work.frames,
@@ -388,7 +437,7 @@ def main():
             "bytes_per_picture": nbytes / args.steps / work.frames,
             "bpp": 8.0 * nbytes / args.steps / work.frames / (HEIGHT * WIDTH),
         }
-        if not args.no_roofline:
+        if not args.no_roofline and not fanout:
             out["roofline"] = roofline(work)
         if world == 1 and not args.no_extras:
             others = {}

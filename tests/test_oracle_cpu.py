@@ -47,6 +47,10 @@ def test_oracle_follows_reference_graph(golden):
         p = psnr(r["x_hat"], ref)
         print("case", i, "PSNR oracle vs reference graph: %.2f dB" % p)
         assert p > 45.0
+        # north_star's tolerance: the picture quality (PSNR against the source) of the fp16 matrix-core path is within
+        # 0.02 dB of the reference's fp32 graph
+        src = x.astype(np.float32)
+        assert abs(psnr(r["x_hat"], src) - psnr(ref, src)) <= 0.02
 
 
 @pytest.mark.parametrize("hw,qp", [((64, 64), 32), ((40, 72), 0)])
@@ -315,3 +319,30 @@ def test_compress_without_gpu_fails_loudly():
     with pytest.raises(Exception):
         p = ext.DMCIProxy()
         p.compress(torch.zeros((1, 3, 64, 64), dtype=torch.float16), 0, 0, 0)
+
+
+def test_symbol_math_matches_the_references_python_fallbacks(golden_dir):
+    """oracle/symbols_np.py against vectors made with DCVC-RT's PyTorch fallbacks of the same kernels
+    (DCVC-family/DCVC-RT/src/layers/cuda_inference.py:26-33,58-74,113-119,124-171; generator:
+    tests/golden/make_symbols_golden.py), on inputs without rounding ties. Bit-exact."""
+    from oracle import symbols_np as sym
+    g = np.load(os.path.join(golden_dir, "symbols_rt_golden.npz"))
+    for case in range(4):
+        y, means, scales, thres = g["y%d" % case], g["means%d" % case], g["scales%d" % case], float(g["thres%d" % case])
+        H, W, C = y.shape
+        for k, mask in enumerate(sym.get_mask_4x(H, W, C)):
+            tag = "%d_%d" % (case, k)
+            y_q, y_hat, s_hat = sym.process_with_mask(y, scales, means, mask, thres)
+            for name, got in (("y_q", y_q), ("y_hat", y_hat), ("s_hat", s_hat)):
+                assert np.array_equal(got, g[name + tag]), (name, tag)    # values (-0.0 == 0.0: the sign of zero is not coded)
+            s_w, y_w = sym.fold4(s_hat), sym.fold4(y_q)
+            idx, keep = sym.build_index_dec(s_w, thres)
+            assert np.array_equal(keep.reshape(H, W, C // 4), g["keep" + tag])
+            assert np.array_equal(idx.reshape(H, W, C // 4), g["idx" + tag])
+            comb, keep_e = sym.build_index_enc(y_w, s_w, thres)
+            assert np.array_equal(keep_e, keep)
+            assert np.array_equal(comb[keep_e], g["comb" + tag])
+            if k == 0:
+                assert np.array_equal(sym.restore_y_4x(sym.fold4(y_q), means, mask), g["restored" + tag])
+        z_hat, z_i8 = sym.round_z(g["z%d" % case])
+        assert np.array_equal(z_hat, g["z_hat%d" % case]) and np.array_equal(z_i8, g["z_i8%d" % case])

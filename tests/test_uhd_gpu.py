@@ -2,10 +2,8 @@
 the 1080p tests (encode -> bytes -> decode closure, encoder / decoder lock-step of the temporal
 state, finite in-range reconstructions) at 4K, for the intra, LD and HT-S codecs.
 
-OPT-IN (DCVC_TEST_UHD=1): written at the end of round 1 after the GPU budget was spent - these
-have not run on hardware yet, so they are kept out of the default `-m gpu` run until they have."""
+Part of the default `-m gpu` run (first run on hardware in round 2: gpurun session 1, all three pass; ~15 s)."""
 import copy
-import os
 
 import numpy as np
 import pytest
@@ -13,8 +11,7 @@ import torch
 
 from codec_util import dmc_ht_model, dmc_ld_model, dmci_model, picture, to_device_input
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("DCVC_TEST_UHD"), reason="opt-in: DCVC_TEST_UHD=1 (not yet run on hardware)")]
+pytestmark = pytest.mark.gpu
 
 H, W = 2160, 3840
 H16, W16 = 2160, 3840           # both multiples of 16: no padding at 4K
