@@ -9,6 +9,7 @@
 #include "codec/modules.h"
 #include "rans/rans_coder.h"
 
+#include <initializer_list>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -96,7 +97,14 @@ protected:
     void load_cdf_tables(const ParamStore& ps);   // both coders, z = table 0, y = table 1
     const half_t* upload_qp_table(const ParamStore& ps, DeviceArena& mem, const char* name, int ch);
     // per-qp scale vector -> fixed device slot, so that one graph serves all 64 qps
-    static void copy_qp_row(half_t* dst, const half_t* table, int qp, int ch, hipStream_t st);
+    // (ONE launch for all the vectors of a codec: the 3-4 separate 1 KB device copies of round 1 showed up as
+    // 8 copy launches per coded picture in the kernel trace)
+    struct QpRow {
+        half_t* dst;
+        const half_t* table;
+        int ch;
+    };
+    static void copy_qp_rows(std::initializer_list<QpRow> rows, int qp, hipStream_t st);
 
     RansEncoder m_enc;
     RansDecoder m_dec;

@@ -183,11 +183,35 @@ const half_t* CodecBase::upload_qp_table(const ParamStore& ps, DeviceArena& mem,
     return mem.upload(t.h);
 }
 
-void CodecBase::copy_qp_row(half_t* dst, const half_t* table, int qp, int ch, hipStream_t st)
+namespace {
+struct QpRowsArg {
+    half_t* dst[4];
+    const half_t* src[4];
+    int ch[4];
+};
+
+// block b copies row b: at most 4 rows of at most a few hundred channels - one tiny launch
+__global__ void copy_qp_rows_kernel(const QpRowsArg a)
+{
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < a.ch[r]; c += blockDim.x) a.dst[r][c] = a.src[r][c];
+}
+}  // namespace
+
+void CodecBase::copy_qp_rows(std::initializer_list<QpRow> rows, int qp, hipStream_t st)
 {
     if (qp < 0 || qp >= kQpNum) throw std::invalid_argument("qp out of range [0, 63]");
-    hip_check(hipMemcpyAsync(dst, table + static_cast<size_t>(qp) * ch, ch * sizeof(half_t),
-                             hipMemcpyDeviceToDevice, st), "select qp");
+    if (rows.size() == 0 || rows.size() > 4) throw std::invalid_argument("copy_qp_rows: 1..4 rows");
+    QpRowsArg a{};
+    int n = 0;
+    for (const QpRow& r : rows) {
+        a.dst[n] = r.dst;
+        a.src[n] = r.table + static_cast<size_t>(qp) * r.ch;
+        a.ch[n] = r.ch;
+        ++n;
+    }
+    hipLaunchKernelGGL(copy_qp_rows_kernel, dim3(n), dim3(256), 0, st, a);
+    hip_check(hipGetLastError(), "copy_qp_rows");
 }
 
 }  // namespace dcvc

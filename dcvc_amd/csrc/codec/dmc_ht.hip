@@ -143,9 +143,8 @@ void DmcHtCodec::prepare(int height, int width)
 
 void DmcHtCodec::select_qp(int qp, hipStream_t st)
 {
-    copy_qp_row(m_cur_q_encoder, m_q_encoder, qp, kChD, st);
-    copy_qp_row(m_cur_q_decoder, m_q_decoder, qp, kChD, st);
-    copy_qp_row(m_cur_q_feature, m_q_feature, qp, kChD, st);
+    copy_qp_rows({{m_cur_q_encoder, m_q_encoder, kChD}, {m_cur_q_decoder, m_q_decoder, kChD},
+                  {m_cur_q_feature, m_q_feature, kChD}}, qp, st);
 }
 
 // ------------------------------------------------------------------------------------ networks

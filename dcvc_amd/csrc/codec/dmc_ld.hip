@@ -131,9 +131,8 @@ void DmcLdCodec::prepare(int height, int width)
 
 void DmcLdCodec::select_qp(int qp, hipStream_t st)
 {
-    copy_qp_row(m_cur_q_encoder, m_q_encoder, qp, kChD, st);
-    copy_qp_row(m_cur_q_decoder, m_q_decoder, qp, kChD, st);
-    copy_qp_row(m_cur_q_feature, m_q_feature, qp, 2 * kChY, st);
+    copy_qp_rows({{m_cur_q_encoder, m_q_encoder, kChD}, {m_cur_q_decoder, m_q_decoder, kChD},
+                  {m_cur_q_feature, m_q_feature, 2 * kChY}}, qp, st);
 }
 
 // ------------------------------------------------------------------------------------ networks

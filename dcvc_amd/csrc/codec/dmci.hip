@@ -4,6 +4,10 @@
 // device->host transfer of the compacted symbols of all four steps.
 #include "codec/dmci.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 
@@ -115,10 +119,8 @@ void DmciCodec::prepare(int height, int width)
 
 void DmciCodec::select_qp(int qp, hipStream_t st)
 {
-    copy_qp_row(m_cur_q_enc, m_q_enc, qp, kChEncDec, st);
-    copy_qp_row(m_cur_q_dec, m_q_dec, qp, kChEncDec, st);
-    copy_qp_row(m_cur_q_y_enc, m_q_y_enc, qp, kChY, st);
-    copy_qp_row(m_cur_q_y_dec, m_q_y_dec, qp, kChY, st);
+    copy_qp_rows({{m_cur_q_enc, m_q_enc, kChEncDec}, {m_cur_q_dec, m_q_dec, kChEncDec},
+                  {m_cur_q_y_enc, m_q_y_enc, kChY}, {m_cur_q_y_dec, m_q_y_dec, kChY}}, qp, st);
 }
 
 // ------------------------------------------------------------------------------------ networks
@@ -294,7 +296,16 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
     m_dec.set_stream(bits, nbytes);
     const int nz = g.P64() * kChZ;
     const int nq = g.P16() * (kChY / 4);
+    // DCVC_TIMING: where a decompress() call spends its host time (f3: the entropy decoder's share)
+    static const bool trace = getenv("DCVC_TIMING") != nullptr;
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
+    const auto t_call = clk::now();
+    double us_rans = 0, us_wait = 0;
+    long n_sym = 0;
+    auto t_z = clk::now();
     m_dec.decode_z(nz, qp * kChZ, kChZ, m_h_z.get());
+    us_rans += us_since(t_z);
     hip_check(hipMemcpyAsync(m_ZI8, m_h_z.get(), nz, hipMemcpyHostToDevice, st), "H2D z");
 
     auto index_step = [&](int k) {
@@ -314,14 +325,21 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
     int base = 0;
     for (int k = 0; k < 4; ++k) {
         // one GPU -> CPU -> GPU round trip per autoregressive step (dmci_proxy.cpp:857-871)
+        auto t_w = clk::now();
         hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
         hip_check(hipStreamSynchronize(st), "sync");
         const int n = m_h_totals[k];
         if (n > 0) {
             hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX + base, n, hipMemcpyDeviceToHost, st), "D2H indexes");
             hip_check(hipStreamSynchronize(st), "sync");
+            us_wait += us_since(t_w);
+            auto t_r = clk::now();
             m_dec.decode_y(m_h_idx.get(), n, m_h_dec.get() + base);
+            us_rans += us_since(t_r);
+            n_sym += n;
             hip_check(hipMemcpyAsync(m_DECODED + base, m_h_dec.get() + base, n, hipMemcpyHostToDevice, st), "H2D symbols");
+        } else {
+            us_wait += us_since(t_w);
         }
         base += n;
         run_stage(kDec1 + k, st, [&] {
@@ -339,6 +357,10 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
                 run_decoder(x_hat, st);
             }
         });
+    }
+    if (trace) {
+        fprintf(stderr, "[dcvc] decompress host %.0f us: entropy decoding %.0f us (%ld y symbols, %zu bytes, %d streams), "
+                        "waiting for the GPU %.0f us\n", us_since(t_call), us_rans, n_sym, nbytes, ec_parallel, us_wait);
     }
     leave(user);
 }

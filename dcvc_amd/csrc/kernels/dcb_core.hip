@@ -369,7 +369,7 @@ dcb_core_kernel(const CoreParams p)
             head[2] = frag_d(ws, 0, 1); head[3] = frag_d(ws, 1, 1);
         }
     };
-    auto step_wide = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[4], auto&& piece,
+    auto step_wide = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[4], auto&& pre, auto&& piece,
                          auto vtag, auto extra) {
         constexpr int valu_per_mfma = decltype(vtag)::value;
         const Pending nx = step_top(g, slot, extra);
@@ -386,6 +386,7 @@ dcb_core_kernel(const CoreParams p)
             } else if constexpr (decltype(next_tag)::value >= 0) {
                 load_head(next_tag, smem + ((slot + 1) % NS) * SLAB);
             }
+            pre(s);
             const half8 b = bfrag(s);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -401,7 +402,7 @@ dcb_core_kernel(const CoreParams p)
             SLICE_FENCE();
         }
     };
-    auto step_deep = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[2], auto&& piece,
+    auto step_deep = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[2], auto&& pre, auto&& piece,
                          auto vtag, auto extra) {
         constexpr int valu_per_mfma = decltype(vtag)::value;
         const Pending nx = step_top(g, slot, extra);
@@ -417,6 +418,7 @@ dcb_core_kernel(const CoreParams p)
             } else if (s == 6) {
                 if constexpr (decltype(next_tag)::value >= 0) load_head(next_tag, smem + ((slot + 1) % NS) * SLAB);
             }
+            pre(s);
             const half8 b = bfrag(s);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][0], b, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][1], b, acc[1], 0, 0, 0);
@@ -507,7 +509,7 @@ dcb_core_kernel(const CoreParams p)
             // follow each of them they are younger than the slab the barrier certifies
             auto run = [&](auto have, auto next, auto extra) {
                 step_wide(g, (3 * ks + c) % NS, have, next, [&](int s) { return bf[ks * 4 + s]; },
-                          *reinterpret_cast<float16v(*)[4]>(&acc2[4 * c]), no_piece, std::integral_constant<int, 0>{}, extra);
+                          *reinterpret_cast<float16v(*)[4]>(&acc2[4 * c]), no_piece, no_piece, std::integral_constant<int, 0>{}, extra);
             };
             using X0 = std::integral_constant<int, 0>;
             using X8 = std::integral_constant<int, 8>;
@@ -563,24 +565,45 @@ dcb_core_kernel(const CoreParams p)
     };
     auto parked = [&](int unit) { return *reinterpret_cast<const float4v*>(dump + unit * 1024 + lane * 16); };
     half8 t3[4], t3n;
-    // epilogue piece q (0..7) of the pair in `prev`; q == 8: combine into a B fragment
-    auto ffn0_piece = [&](int q, half8& out) {
-        if (q < 8) {
-            const int hh = q >> 2, g4 = q & 3;
-            const float4v v4 = parked(q);
-            float v[4];
+    // Epilogue of the parked pair, 8 pieces of 4 values + one combine. A piece is two DEPENDENT LDS round
+    // trips (parked values -> table index -> coefficient gather -> polynomial); issued in one go behind the
+    // MFMAs of a slice, the wave sat out both latencies with the matrix pipe idle after ~128 cycles
+    // (measured: every interleaved piece cost its full ~300 cycles). In stages, each one slice apart from
+    // the data it needs:  read (in front of the slice's MFMAs) | index + gather (behind them) | polynomial
+    // + chunk sum (behind the MFMAs of the NEXT slice).
+    float4v pv[2];                 // parked values of the pieces being read / indexed (q & 1)
+    float ev[2][4], ef[2][4];      // values / table fractions of the pieces whose coefficients are in flight (q & 1)
+    float4 ec[2][4];
+    auto piece_read = [&](int q) { pv[q & 1] = parked(q); };
+    auto piece_index = [&](int q) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v4[e];
-            wsilu_n<4, R>(v, tab);
-            sums[hh][g4] = ((v[0] + v[1]) + v[2]) + v[3];
-        } else if (q == 8) {
+        for (int e = 0; e < 4; ++e) {
+            ev[q & 1][e] = pv[q & 1][e];
+            float t = fmaf(pv[q & 1][e], 16.0f, 128.0f);
+            t = fminf(fmaxf(t, 0.0f), 255.99998f);
+            ef[q & 1][e] = __builtin_amdgcn_fractf(t);
+            ec[q & 1][e] = tab[static_cast<int>(t) * R];
+        }
+    };
+    auto piece_poly = [&](int q) {
+        float v[4];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sums[0][g4]),
-                                                                 __float_as_uint(sums[1][g4]), false, false);
-                out[2 * g4] = to_half(__uint_as_float(sw[0]));
-                out[2 * g4 + 1] = to_half(__uint_as_float(sw[1]));
-            }
+        for (int e = 0; e < 4; ++e) {
+            const float f = ef[q & 1][e];
+            float pp = fmaf(ec[q & 1][e].w, f, ec[q & 1][e].z);
+            pp = fmaf(pp, f, ec[q & 1][e].y);
+            pp = fmaf(pp, f, ec[q & 1][e].x);
+            v[e] = ev[q & 1][e] * pp;
+        }
+        sums[q >> 2][q & 3] = ((v[0] + v[1]) + v[2]) + v[3];
+    };
+    auto piece_combine = [&](half8& out) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sums[0][g4]),
+                                                             __float_as_uint(sums[1][g4]), false, false);
+            out[2 * g4] = to_half(__uint_as_float(sw[0]));
+            out[2 * g4 + 1] = to_half(__uint_as_float(sw[1]));
         }
     };
     // 3 deep slabs of one ffn.0 channel pair (first channel `ch0`), with the epilogue of the previous
@@ -593,9 +616,14 @@ dcb_core_kernel(const CoreParams p)
             auto body = [&](auto have, auto next) {
                 step_deep(g, (slot0 + k3) % NS, have, next, [&](int s) { return bf[8 * k3 + s]; }, cur,
                           [&](int s) {
-                              const int slot24 = 8 * k3 + s;            // one piece every third slice, combine last
-                              if (with_prev && slot24 % 3 == 1) ffn0_piece(slot24 / 3, out);
-                              if (with_prev && slot24 == 23) ffn0_piece(8, out);
+                              const int slot24 = 8 * k3 + s;            // piece q: read in slice 3q, index in 3q+1, polynomial in 3q+2
+                              if (with_prev && slot24 % 3 == 0) piece_read(slot24 / 3);
+                          },
+                          [&](int s) {
+                              const int slot24 = 8 * k3 + s;
+                              if (with_prev && slot24 % 3 == 1) piece_index(slot24 / 3);
+                              if (with_prev && slot24 % 3 == 2) piece_poly(slot24 / 3);
+                              if (with_prev && slot24 == 23) piece_combine(out);
                           }, std::integral_constant<int, 10>{}, std::integral_constant<int, 0>{});
             };
             if (k3 == 0) body(have_head, TagD{});
@@ -613,9 +641,15 @@ dcb_core_kernel(const CoreParams p)
                 step_wide(g, (slot0 + nc) % NS, have, next, [&](int s) { return tt[s]; },
                           *reinterpret_cast<float16v(*)[4]>(&acc2[4 * nc]),
                           [&](int s) {
+                              const int slot12 = 4 * nc + s;            // piece q: read in slice q-1, index in q, polynomial in q+1
+                              if (with_prev && slot12 == 0) piece_read(0);
+                              if (with_prev && slot12 + 1 < 8) piece_read(slot12 + 1);
+                          },
+                          [&](int s) {
                               const int slot12 = 4 * nc + s;
-                              if (with_prev && slot12 < 8) ffn0_piece(slot12, out);
-                              if (with_prev && slot12 == 8) ffn0_piece(8, out);
+                              if (with_prev && slot12 < 8) piece_index(slot12);        // gathers go out first ...
+                              if (with_prev && slot12 >= 1 && slot12 <= 8) piece_poly(slot12 - 1);     // ... the previous piece's are there
+                              if (with_prev && slot12 == 8) piece_combine(out);
                           }, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
             };
             if (nc == 0) body(have_head, TagW{});
@@ -626,7 +660,12 @@ dcb_core_kernel(const CoreParams p)
     };
     auto finish_prev = [&](half8& out) {       // epilogue of the parked pair, not overlapped
 #pragma unroll
-        for (int q = 0; q <= 8; ++q) ffn0_piece(q, out);
+        for (int q = 0; q < 8; ++q) {
+            piece_read(q);
+            piece_index(q);
+            piece_poly(q);
+        }
+        piece_combine(out);
     };
 
     stamp();                                         // 2: y1 epilogue done
@@ -693,28 +732,43 @@ dcb_core_kernel(const CoreParams p)
     // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')
     if (p.w1n != nullptr) {
         half8 o4[4];
-        // epilogue run r (tile r>>1, half r&1) of the pair in `prev`; r == 4: the pair's 64 channels go out
-        auto dc0_piece = [&](int r, int first) {
-            if (r < 4) {
-                // run r = (tile r>>1, half r&1): parked units 2 (r&1) and 2 (r&1) + 1 of that tile, half-waves paired
-                const float4v lo4 = parked((r >> 1) * 4 + 2 * (r & 1));
-                const float4v hi4 = parked((r >> 1) * 4 + 2 * (r & 1) + 1);
-                float v[8];
+        // epilogue run r (tile r>>1, half r&1) of the parked pair, in the same three stages as the ffn.0 pieces
+        // (read | index + gather | polynomial, one slice apart); dc0_flush: the pair's 64 channels go out
+        float4v dlo, dhi;
+        float dv[8], df[8];
+        float4 dc[8];
+        auto dc0_read = [&](int r) {
+            // run r = (tile r>>1, half r&1): parked units 2 (r&1) and 2 (r&1) + 1 of that tile, half-waves paired
+            dlo = parked((r >> 1) * 4 + 2 * (r & 1));
+            dhi = parked((r >> 1) * 4 + 2 * (r & 1) + 1);
+        };
+        auto dc0_index = [&]() {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo4[e]), __float_as_uint(hi4[e]), false, false);
-                    v[e] = __uint_as_float(sw[0]);
-                    v[4 + e] = __uint_as_float(sw[1]);
-                }
-                wsilu_n<8, R>(v, tab);
-                half8 o;
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dlo[e]), __float_as_uint(dhi[e]), false, false);
+                dv[e] = __uint_as_float(sw[0]);
+                dv[4 + e] = __uint_as_float(sw[1]);
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-                o4[r] = o;
-            } else if (r == 4) {
-                flush(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first);
+            for (int e = 0; e < 8; ++e) {
+                float t = fmaf(dv[e], 16.0f, 128.0f);
+                t = fminf(fmaxf(t, 0.0f), 255.99998f);
+                df[e] = __builtin_amdgcn_fractf(t);
+                dc[e] = tab[static_cast<int>(t) * R];
             }
         };
+        auto dc0_poly = [&](int r) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float pp = fmaf(dc[e].w, df[e], dc[e].z);
+                pp = fmaf(pp, df[e], dc[e].y);
+                pp = fmaf(pp, df[e], dc[e].x);
+                o[e] = to_half(dv[e] * pp);
+            }
+            o4[r] = o;
+        };
+        auto dc0_flush = [&](int first) { flush(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first); };
         auto dc0_pair = [&](int j, auto have_head, bool with_prev) {
             bias_tile(cur[0], lb1n, 64 * j);
             bias_tile(cur[1], lb1n, 64 * j + 32);
@@ -723,9 +777,14 @@ dcb_core_kernel(const CoreParams p)
                 auto body = [&](auto have) {
                     step_deep(g, g % NS, have, TagD{}, [&](int s) { return bf[8 * k3 + s]; }, cur,
                               [&](int s) {
+                                  const int slot24 = 8 * k3 + s;            // run r: read in slice 5r+1, index in 5r+2, polynomial in 5r+3
+                                  if (with_prev && slot24 % 5 == 1 && slot24 < 20) dc0_read(slot24 / 5);
+                              },
+                              [&](int s) {
                                   const int slot24 = 8 * k3 + s;
-                                  if (with_prev && slot24 % 5 == 2 && slot24 < 20) dc0_piece(slot24 / 5, 64 * (j - 1));
-                                  if (with_prev && slot24 == 22) dc0_piece(4, 64 * (j - 1));
+                                  if (with_prev && slot24 % 5 == 2 && slot24 < 20) dc0_index();
+                                  if (with_prev && slot24 % 5 == 3 && slot24 < 20) dc0_poly(slot24 / 5);
+                                  if (with_prev && slot24 == 22) dc0_flush(64 * (j - 1));
                               }, std::integral_constant<int, 10>{}, std::integral_constant<int, 0>{});
                 };
                 if (k3 == 0) body(have_head); else body(Yes{});
@@ -736,7 +795,12 @@ dcb_core_kernel(const CoreParams p)
         dc0_pair(0, No{}, false);
         for (int j = 1; j < 6; ++j) dc0_pair(j, Yes{}, true);
 #pragma unroll
-        for (int r = 0; r <= 4; ++r) dc0_piece(r, 64 * 5);
+        for (int r = 0; r < 4; ++r) {
+            dc0_read(r);
+            dc0_index();
+            dc0_poly(r);
+        }
+        dc0_flush(64 * 5);
     }
     // the prefetches behind the last slab are still on their way into this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

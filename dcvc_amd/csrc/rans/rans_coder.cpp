@@ -108,18 +108,28 @@ inline int8_t dec_symbol(DecState& s, const CdfTable& t, int cdf_idx)
     const uint32_t* cdf = t.cdf.data() + static_cast<size_t>(cdf_idx) * t.stride;
     const int32_t max_value = t.max_value[cdf_idx];
     const uint32_t cum = s.r & kProbMask;
-    int v = 0;
+    int v = t.first.empty() ? 0 : t.first[static_cast<size_t>(cdf_idx) * 256 + (cum >> 8)];
     while (cdf[v + 1] <= cum) {
         ++v;
     }
     const uint32_t start = cdf[v];
     const uint32_t freq = cdf[v + 1] - start;
-    s.r = freq * (s.r >> kRansProbBits) + cum - start;
-    while (s.r < kRansLow) {
-        s.r = (s.r << 8) | dec_byte(s);
+    uint32_t r = freq * (s.r >> kRansProbBits) + cum - start;
+    // renormalisation without a data-dependent branch: r >= 2^7 here (freq >= 1, state >= 2^23), so 0, 1
+    // or 2 bytes bring it back above 2^23; whether a byte is needed is close to a coin flip per symbol
+    if (s.end - s.p >= 2) {
+        const uint32_t n = static_cast<uint32_t>(r < kRansLow) + static_cast<uint32_t>(r < (kRansLow >> 8));
+        const uint32_t two = (static_cast<uint32_t>(s.p[0]) << 8) | s.p[1];
+        r = (r << (8 * n)) | (two >> (16 - 8 * n));
+        s.p += n;
+    } else {
+        while (r < kRansLow) {
+            r = (r << 8) | dec_byte(s);
+        }
     }
+    s.r = r;
     int32_t value = v;
-    if (value == max_value) {
+    if (__builtin_expect(value == max_value, 0)) {
         uint32_t g = dec_bits(s);
         uint32_t n_groups = g;
         while (g == kBypassMax) {
@@ -211,6 +221,19 @@ void CdfTable::load(const int32_t* cdfs, int num_cdf, int row_stride, const int3
                 }
                 rcp[e] = static_cast<uint32_t>(((1ull << (shift + 31)) + f - 1) / f);
                 rcp_shift[e] = static_cast<uint8_t>(shift - 1);
+            }
+        }
+    }
+    first.clear();
+    if (num <= kLutRows && kRansProbBits == 16) {
+        first.assign(static_cast<size_t>(num) * 256, 0);
+        for (int i = 0; i < num; ++i) {
+            const uint32_t* row = cdf.data() + static_cast<size_t>(i) * stride;
+            const int last = cdf_sizes[i] - 2;              // the scan never has to pass the escape value
+            int v = 0;
+            for (uint32_t b = 0; b < 256; ++b) {
+                while (v < last && row[v + 1] <= (b << 8)) ++v;
+                first[static_cast<size_t>(i) * 256 + b] = static_cast<uint8_t>(v);
             }
         }
     }

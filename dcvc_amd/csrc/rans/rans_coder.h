@@ -36,6 +36,11 @@ struct CdfTable {
     std::vector<uint8_t> rcp_shift;    // [num*stride]
     std::vector<uint32_t> cdf;         // [num*stride] raw cumulative values (decoder)
     std::vector<int8_t> max_value;     // [num] escape value = cdf_length - 2
+    // decoder search start: first[i*256 + (cum >> 8)] = the value whose interval holds (cum & ~255), so
+    // the scan for cum starts there instead of at 0 (built for families of at most kLutRows rows: the
+    // 128 Gaussian tables = 32 KB, L1-resident; the per-channel z tables code ~1 % of the symbols)
+    static constexpr int kLutRows = 256;
+    std::vector<uint8_t> first;
     void load(const int32_t* cdfs, int num_cdf, int row_stride, const int32_t* cdf_sizes);
 };
 

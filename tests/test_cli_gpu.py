@@ -15,6 +15,7 @@ import torch
 
 from codec_util import dmc_ht_model, dmc_ld_model, dmci_model
 from dcvc_amd import _lib, export_weights, stream_helper as sh, synthetic
+from oracle import frame_io
 
 pytestmark = pytest.mark.gpu
 
@@ -71,7 +72,9 @@ def _python_reference(frames, H, W, i_model, p_model, delay, qp_i, qp_p, reset_i
     helper = sh.SPSHelper()
 
     def x_of(idx_list):
-        xs = [synthetic.yuv420_to_x(*frames[i]).half().cuda() for i in idx_list]
+        # the picture conversion of the harness (test_video.py:69-123: u8 -> fp16 / 255 -> - 0.5, every step in fp16),
+        # which is what the tool's yuv420_to_x kernel does; restated in oracle/frame_io.py
+        xs = [torch.from_numpy(frame_io.yuv420_to_x(*frames[i])).permute(2, 0, 1)[None].cuda() for i in idx_list]
         return torch.cat(xs, dim=1).contiguous(memory_format=torch.channels_last)
 
     n, idx = len(frames), 0
