@@ -334,8 +334,17 @@ dcb_core_kernel(const CoreParams p)
     // piece(s): VALU work (the epilogue of an EARLIER accumulator set) placed behind the MFMAs of k-slice s.
     // `extra`: register-destination loads issued within the last three steps (they sit between the
     // stream's own operations in the in-order queue and must not be mistaken for them)
+    // A NEGATIVE `extra` = that many global STORES (gfx950 counts stores in vmcnt too): a row store is skipped
+    // when none of its rows exists, so only a wave whose 32 pixels are all inside the picture may count on them.
+    const bool wave_full = m0 + 32 <= p.M;
     auto step_top = [&](int g, int slot, auto extra) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS + decltype(extra)::value) : "memory");
+        constexpr int ex = decltype(extra)::value;
+        if constexpr (ex >= 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS + ex) : "memory");
+        } else {
+            if (wave_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS - ex) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -769,12 +778,15 @@ dcb_core_kernel(const CoreParams p)
             o4[r] = o;
         };
         auto dc0_flush = [&](int first) { flush(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first); };
-        auto dc0_pair = [&](int j, auto have_head, bool with_prev) {
+        // `stores`: row stores (negative count, see step_top) younger than the slabs the first steps certify - the
+        // flush of the previous pair sits behind 3 of the 4 prefetch pieces of the step before, the y epilogue
+        // behind all of them
+        auto dc0_pair = [&](int j, auto have_head, bool with_prev, auto st0, auto st1, auto st2) {
             bias_tile(cur[0], lb1n, 64 * j);
             bias_tile(cur[1], lb1n, 64 * j + 32);
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
-                auto body = [&](auto have) {
+                auto body = [&](auto have, auto stores) {
                     step_deep(g, g % NS, have, TagD{}, [&](int s) { return bf[8 * k3 + s]; }, cur,
                               [&](int s) {
                                   const int slot24 = 8 * k3 + s;            // run r: read in slice 5r+1, index in 5r+2, polynomial in 5r+3
@@ -785,15 +797,21 @@ dcb_core_kernel(const CoreParams p)
                                   if (with_prev && slot24 % 5 == 2 && slot24 < 20) dc0_index();
                                   if (with_prev && slot24 % 5 == 3 && slot24 < 20) dc0_poly(slot24 / 5);
                                   if (with_prev && slot24 == 22) dc0_flush(64 * (j - 1));
-                              }, std::integral_constant<int, 10>{}, std::integral_constant<int, 0>{});
+                              }, std::integral_constant<int, 10>{}, stores);
                 };
-                if (k3 == 0) body(have_head); else body(Yes{});
+                if (k3 == 0) body(have_head, st0);
+                else if (k3 == 1) body(Yes{}, st1);
+                else body(Yes{}, st2);
                 ++g;
             }
             park(cur);
         };
-        dc0_pair(0, No{}, false);
-        for (int j = 1; j < 6; ++j) dc0_pair(j, Yes{}, true);
+        using S0 = std::integral_constant<int, 0>;
+        using S4 = std::integral_constant<int, -4>;          // one 64-channel flush = 4 row stores per lane
+        using S24 = std::integral_constant<int, -24>;        // the y epilogue = 3 x 8
+        dc0_pair(0, No{}, false, S24{}, S24{}, S24{});
+        dc0_pair(1, Yes{}, true, S0{}, S0{}, S0{});
+        for (int j = 2; j < 6; ++j) dc0_pair(j, Yes{}, true, S4{}, S4{}, S0{});
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dc0_read(r);

@@ -3,6 +3,9 @@
 // groups, value mapping) and py_rans.cpp:104-249,412-492 (splitting + container).
 #include "rans_coder.h"
 
+#include <chrono>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cassert>
 #include <cstring>
@@ -240,8 +243,18 @@ void CdfTable::load(const int32_t* cdfs, int num_cdf, int row_stride, const int3
 }
 
 // ------------------------------------------------------------------------ WorkerPool
+namespace {
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+}  // namespace
+
 WorkerPool::WorkerPool(int threads)
 {
+    if (const char* e = getenv("DCVC_RANS_SPIN_US")) m_spin_us = atoi(e);
     for (int i = 0; i < threads; ++i) {
         m_threads.emplace_back(&WorkerPool::loop, this, i);
     }
@@ -282,11 +295,22 @@ void WorkerPool::loop(int)
             if (err && !m_error) {
                 m_error = err;
             }
-            if (--m_pending == 0) {
+            m_pending_hint.store(--m_pending, std::memory_order_release);
+            if (m_pending == 0) {
                 m_cv_done.notify_all();
             }
         }
         seen = m_epoch;
+        if (m_spin_us > 0 && !m_stop) {
+            // stay hot for a while: the next run() of the same picture is usually close
+            lk.unlock();
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(m_spin_us);
+            while (m_epoch_hint.load(std::memory_order_acquire) == seen) {
+                for (int i = 0; i < 64; ++i) cpu_relax();
+                if (std::chrono::steady_clock::now() >= until) break;
+            }
+            lk.lock();
+        }
     }
 }
 
@@ -308,6 +332,8 @@ void WorkerPool::run(int n, const std::function<void(int)>& fn)
     m_pending = n;
     m_error = nullptr;
     ++m_epoch;
+    m_pending_hint.store(n, std::memory_order_release);
+    m_epoch_hint.store(m_epoch, std::memory_order_release);
     lk.unlock();
     m_cv_work.notify_all();
     // a failing item (bad_alloc, corrupt stream) must neither terminate a pool thread nor leave
@@ -323,14 +349,23 @@ void WorkerPool::run(int n, const std::function<void(int)>& fn)
     m_local_error = nullptr;
     guarded(0);
     lk.lock();
-    --m_pending;
+    m_pending_hint.store(--m_pending, std::memory_order_release);
     // help with whatever the workers have not picked up yet
     while (m_next < m_n) {
         const int item = m_next++;
         lk.unlock();
         guarded(item);
         lk.lock();
-        --m_pending;
+        m_pending_hint.store(--m_pending, std::memory_order_release);
+    }
+    if (m_pending != 0 && m_spin_us > 0) {
+        lk.unlock();
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(m_spin_us);
+        while (m_pending_hint.load(std::memory_order_acquire) > 0) {
+            for (int i = 0; i < 64; ++i) cpu_relax();
+            if (std::chrono::steady_clock::now() >= until) break;
+        }
+        lk.lock();
     }
     m_cv_done.wait(lk, [&] { return m_pending == 0; });
     m_fn = nullptr;

@@ -10,6 +10,7 @@
 // (the reference keeps one thread + queue per sub-stream object).
 #pragma once
 
+#include <atomic>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
@@ -61,6 +62,12 @@ private:
     int m_n = 0, m_next = 0, m_pending = 0;
     uint64_t m_epoch = 0;
     bool m_stop = false;
+    // lock-free mirrors of m_epoch / m_pending for the bounded spin in front of the condition-variable waits:
+    // a picture is decoded in five short run() calls a few hundred microseconds apart, and a sleeping worker
+    // costs 50-90 us of wake-up latency per call (measured) - more than the coding work of a small step
+    std::atomic<uint64_t> m_epoch_hint{0};
+    std::atomic<int> m_pending_hint{0};
+    int m_spin_us = 1000;              // DCVC_RANS_SPIN_US; 0 = always sleep
     std::exception_ptr m_error, m_local_error;      // first failure of a run(), rethrown by run()
     std::mutex m_err_mu;
 };

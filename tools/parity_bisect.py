@@ -184,8 +184,22 @@ def main():
         call(ops.conv_kxk, ptr(xd), C, ptr(wd), ptr(bd), ptr(y), cout, H, W, C, cout, ksize, stride, pad, stream())
         torch.cuda.synchronize()
         state["n"] += 1
+        xh = np.ascontiguousarray(x, dtype=np.float16)
+
+        def detail(i):
+            ho, wo, c = i
+            row = np.zeros((ksize, ksize, C), dtype=np.float16)       # contraction index (ky, kx, cin)
+            for ky in range(ksize):
+                for kx in range(ksize):
+                    hi, wi = ho * stride - pad + ky, wo * stride - pad + kx
+                    if 0 <= hi < H and 0 <= wi < W:
+                        row[ky, kx] = xh[hi, wi]
+            x_row, w_row = row.reshape(-1), wt[c].reshape(-1)
+            tr = replay(x_row, w_row, np.ascontiguousarray(bias, dtype=np.float16)[c])
+            out = ["channel %d: accumulator after the last 16-blocks: %s" % (c, " ".join("%.9g" % float(t) for t in tr[-4:]))]
+            return out + hardware_chain(x_row, w_row, tr)
         report("op #%d conv %dx%d s%d %dx%dx%d -> %d" % (state["n"], ksize, ksize, stride, H, W, C, cout),
-               y.cpu().numpy(), want)
+               y.cpu().numpy(), want, detail)
         return want
 
     def subpel_conv1x1(x, w):
