@@ -64,6 +64,8 @@ def parse_args():
     p.add_argument("--fanout", action="store_true",
                    help="hts / htl with --gpus N > 1: ONE stream, the 8 reconstruction heads of a chunk spread over the ranks "
                         "(feature_p broadcast over RCCL; strong scaling) instead of N independent streams")
+    p.add_argument("--two-codecs", action="store_true",
+                   help="intra: separate encoder / decoder codec objects (default: one object, as the reference harness)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the short runs of the other three workloads")
@@ -96,11 +98,15 @@ def make_pictures(n, rank, device):
 
 
 class IntraWorkload:
-    """configs[1]: every picture is an I picture."""
+    """configs[1]: every picture is an I picture. One codec object codes and decodes (`dec_net=None`), as the
+    reference harness uses its i_frame_net; `--two-codecs` gives the decoder its own object (own stream: its
+    prior stages then overlap the encoder's reconstruction tail - measured SLOWER, 105.8 vs 119.6 pictures/s:
+    the two streams' full-chip kernels get in each other's way)."""
     frames, kind = 1, "intra"
 
-    def __init__(self, gpu_net, pics, pad_b, pad_r):
+    def __init__(self, gpu_net, pics, pad_b, pad_r, dec_net=None):
         self.net, self.pics, self.pad_b, self.pad_r = gpu_net, pics, pad_b, pad_r
+        self.dec = dec_net if dec_net is not None else gpu_net
         self.sps = {"height": HEIGHT, "width": WIDTH}
 
     def prepare(self, i):
@@ -110,10 +116,11 @@ class IntraWorkload:
         return self.net.compress(self.pics[i % len(self.pics)], qp, self.pad_b, self.pad_r)
 
     def decompress(self, i, qp, enc):
-        return self.net.decompress(enc["bit_stream"], self.sps, qp, enc["ec_parallel"])
+        return self.dec.decompress(enc["bit_stream"], self.sps, qp, enc["ec_parallel"])
 
     def set_use_graphs(self, on):
-        self.net._ensure_proxy().set_use_graphs(on)
+        for g in {id(self.net): self.net, id(self.dec): self.dec}.values():
+            g._ensure_proxy().set_use_graphs(on)
 
     default_graphs = True
 
@@ -382,7 +389,7 @@ def main():
 
     def make_work(kind):
         if kind == "intra":
-            return IntraWorkload(gpu_net, pics, pad_b, pad_r)
+            return IntraWorkload(gpu_net, pics, pad_b, pad_r, _to_gpu(cpu_net, device) if args.two_codecs else None)
         return InterWorkload(kind, device, pics, gpu_net, pad_b, pad_r)
 
     fanout = args.fanout and world > 1
@@ -429,6 +436,7 @@ def main():
                                    + "q_index cycling {0,16,32,48,63}, skip_thres 0.15, one step = compress + decompress of %d "
                                      "picture(s)" % work.frames,
                        "sharding": "recon-head fan-out" if fanout else "independent streams (sharding.shard_range)",
+                       "codec_objects": "one" if (args.workload == "intra" and not args.two_codecs) else "separate encoder / decoder",
                        "pictures_per_step": work.frames, "resolution": "%dx%d" % (WIDTH, HEIGHT)},
             "encode_fps": work.frames / te, "decode_fps": work.frames / td,
             "avg_frame_encoding_time_ms": 1e3 * te / work.frames, "avg_frame_decoding_time_ms": 1e3 * td / work.frames,

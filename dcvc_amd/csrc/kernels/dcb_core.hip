@@ -80,6 +80,11 @@ static_assert(G_CORE + G_D + NS <= SLAB_ENTRIES, "slab table too small");
 #else
 #define SLICE_FENCE()
 #endif
+#ifndef DCB_CORE_NO_LOADS_FENCE
+#define LOADS_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LOADS_FENCE()
+#endif
 enum : int { WIDE = 0, DEEP = 1 };       // slab shapes: [128 rows][64 k] (4 tiles x 4 k-slices) / [64 rows][128 k] (2 x 8)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -396,6 +401,11 @@ dcb_core_kernel(const CoreParams p)
                 load_head(next_tag, smem + ((slot + 1) % NS) * SLAB);
             }
             pre(s);
+            // the reads of the NEXT slice's fragments go out in front of this slice's MFMAs: left alone, hipcc
+            // sinks them behind three of the four MFMAs to recycle the fragment registers, and the next slice
+            // then waits a full LDS round trip with the matrix pipe idle (measured in the ISA: lgkmcnt waits one
+            // MFMA behind their reads)
+            LOADS_FENCE();
             const half8 b = bfrag(s);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -428,6 +438,7 @@ dcb_core_kernel(const CoreParams p)
                 if constexpr (decltype(next_tag)::value >= 0) load_head(next_tag, smem + ((slot + 1) % NS) * SLAB);
             }
             pre(s);
+            LOADS_FENCE();
             const half8 b = bfrag(s);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][0], b, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][1], b, acc[1], 0, 0, 0);

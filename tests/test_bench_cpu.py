@@ -81,6 +81,7 @@ def fake_gpu(monkeypatch):
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
     monkeypatch.setattr(__graft_entry__, "build", lambda: None)
     monkeypatch.setattr(bench, "build_model", lambda device: (_FakeNet(), _FakeNet()))
+    monkeypatch.setattr(bench, "_to_gpu", lambda net, device: _FakeNet())
     monkeypatch.setattr(bench, "make_pictures", lambda n, rank, device: [None] * n)
     monkeypatch.setattr(bench, "IntraWorkload", _FakeWork)
     monkeypatch.setattr(bench, "InterWorkload", _FakeInter)
