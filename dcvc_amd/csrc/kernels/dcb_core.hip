@@ -116,6 +116,12 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 
+// the same with a wave-uniform base and a 32-bit byte offset per lane
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
 template <int N, int RR>
 __device__ __forceinline__ void wsilu_n(float (&v)[N], const float4* tab)
 {
@@ -308,6 +314,14 @@ dcb_core_kernel(const CoreParams p)
         ++stamp_no;
     };
 
+    // fine timeline (TIMELINE launches only): issue times of wave 0 inside two dc.3 steps (slabs 6 and 7) and two
+    // ffn.2 steps of the walk - kept in scalar registers, written at the very end (slots 16.. of the row)
+    unsigned fine_t[24] = {};
+    auto fine = [&](int idx) {
+        if constexpr (TIMELINE) fine_t[idx] = static_cast<unsigned>(__builtin_readcyclecounter());
+    };
+    int flush_probe = -1;            // >= 0: the next flush stamps its stages into fine_t[flush_probe ..]
+
     // A-fragment offsets inside a slab (tile t adds 32 rows)
     // One register per (shape, k-slice); slot and tile are compile-time byte offsets that fold into the
     // ds_read immediate. (Anything computed per (slot, tile, slice) is loop-invariant and gets hoisted:
@@ -386,7 +400,10 @@ dcb_core_kernel(const CoreParams p)
     auto step_wide = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[4], auto&& pre, auto&& piece,
                          auto vtag, auto extra) {
         constexpr int valu_per_mfma = decltype(vtag)::value;
+        const int fbase = (decltype(vtag)::value == 0 && g == 7) ? 0 : -1;     // vtag 0 = the dc.3 steps (fully unrolled: g is a constant there)
+        if (TIMELINE && fbase >= 0) fine(fbase);
         const Pending nx = step_top(g, slot, extra);
+        if (TIMELINE && fbase >= 0) fine(fbase + 1);
         const char* ws = smem + slot * SLAB;
         if constexpr (!decltype(have_head)::value) load_head(std::integral_constant<int, WIDE>{}, ws);
         half8 wf[2][4];
@@ -419,12 +436,17 @@ dcb_core_kernel(const CoreParams p)
             }
             issue_part(nx, s);
             SLICE_FENCE();
+            if (TIMELINE && fbase >= 0) fine(fbase + 2 + s);
         }
     };
     auto step_deep = [&](int g, int slot, auto have_head, auto next_tag, auto&& bfrag, float16v (&acc)[2], auto&& pre, auto&& piece,
                          auto vtag, auto extra) {
         constexpr int valu_per_mfma = decltype(vtag)::value;
+        // vtag 11 = the next block's dc.0; its pair 1 (steps G_CORE + 3 .. + 5) sits outside the loop: g is a constant
+        const int fbase = (valu_per_mfma == 11 && g == G_CORE + 5) ? 18 : -1;
+        if (TIMELINE && fbase >= 0) fine(fbase);
         const Pending nx = step_top(g, slot, extra);
+        if (TIMELINE && fbase >= 0) fine(fbase + 1);
         const char* ws = smem + slot * SLAB;
         if constexpr (!decltype(have_head)::value) load_head(std::integral_constant<int, DEEP>{}, ws);
         half8 wf[3][2];
@@ -452,6 +474,7 @@ dcb_core_kernel(const CoreParams p)
                 }
                 issue_part(nx, s >> 1);
                 SLICE_FENCE();
+                if (TIMELINE && fbase >= 0) fine(fbase + 2 + (s >> 1));
             }
         }
     };
@@ -492,22 +515,44 @@ dcb_core_kernel(const CoreParams p)
         constexpr int CPR = NCH / 8;                       // 16-B chunks per row
         constexpr int STAGE_PITCH = NCH == 128 ? PITCH128 : PITCH64;
         char* const stg = NCH == 128 ? dump : dump + DUMP_BYTES;
+        if (TIMELINE && flush_probe >= 0) fine(flush_probe);
 #pragma unroll
         for (int i = 0; i < CPR / 2; ++i) {                // run i = (tile i/2, pr i%2) -> channels 16 i + 8 hi
             *reinterpret_cast<half8*>(stg + px * STAGE_PITCH + hi * 16 + i * 32) = o[i];
         }
+        if (TIMELINE && flush_probe >= 0) fine(flush_probe + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (TIMELINE && flush_probe >= 0) fine(flush_probe + 2);
         constexpr int RPI = 64 / CPR;                      // rows per iteration
         const int rrow = lane / CPR, rc = lane % CPR;
+        if (wave_full) {
+            // all 32 rows exist: every read first, ONE wait, then the stores. (The guarded form below compiles to
+            // a chain of branch | ds_read | s_waitcnt lgkmcnt(0) | store blocks: one exposed LDS round trip per
+            // row group - measured 1 300 cycles per 64-channel flush, 24 such blocks in the y epilogue.)
+            half8 v[CPR / 2];
 #pragma unroll
-        for (int it = 0; it < CPR / 2; ++it) {
-            const int row = it * RPI + rrow;
-            const half8 v = *reinterpret_cast<const half8*>(stg + rrow * STAGE_PITCH + rc * 16 + it * (RPI * STAGE_PITCH));
-            if (m0 + row < p.M) {
-                store_line(dst + static_cast<size_t>(m0 + row) * ld + first + rc * 8, v);
+            for (int it = 0; it < CPR / 2; ++it)
+                v[it] = *reinterpret_cast<const half8*>(stg + rrow * STAGE_PITCH + rc * 16 + it * (RPI * STAGE_PITCH));
+            if (TIMELINE && flush_probe >= 0) fine(flush_probe + 3);
+            half_t* const row0 = dst + static_cast<size_t>(m0 + rrow) * ld + first + rc * 8;
+            // (timing experiment, TIMELINE launches only: DCVC_CORE_NOSTORE=1 drops the stores)
+            if (!(TIMELINE && (p.shortcut & 2))) {
+#pragma unroll
+                for (int it = 0; it < CPR / 2; ++it) store_line(row0 + static_cast<size_t>(it * RPI) * ld, v[it]);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < CPR / 2; ++it) {
+                const int row = it * RPI + rrow;
+                const half8 v = *reinterpret_cast<const half8*>(stg + rrow * STAGE_PITCH + rc * 16 + it * (RPI * STAGE_PITCH));
+                if (m0 + row < p.M) {
+                    store_line(dst + static_cast<size_t>(m0 + row) * ld + first + rc * 8, v);
+                }
             }
         }
+        if (TIMELINE && flush_probe >= 0) fine(flush_probe + 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (TIMELINE && flush_probe >= 0) fine(flush_probe + 5);
     };
 
     int g = 0;
@@ -519,31 +564,63 @@ dcb_core_kernel(const CoreParams p)
     float16v acc2[12];
 #pragma unroll
     for (int nt = 0; nt < 12; ++nt) bias_tile(acc2[nt], lb3, 32 * nt);
+    // The block input x (residual of dc.3) comes in three 128-channel thirds by LDS-DMA into the wave's own staging
+    // area (free until the ffn walk parks accumulators there), whole 256-B row segments per instruction, bank
+    // swizzle on the source side like the weight slabs, and is read from there in B-fragment layout into the
+    // registers t2 frees up. (Round 2 first loaded it straight into registers, 32 B per row and lane pair: 32
+    // partial lines per instruction - measured 1 800 instead of 780 cycles for every slab step behind such a load.)
+    // Third t goes out behind step {2, 7, 13}: for the three steps that follow, its 8 pieces are younger than the
+    // slab the barrier certifies (extra = 8), the fourth step certifies them; it is read behind step {6, 12, 17}
+    // (the step in between has drained the reads of the previous third before the next one overwrites the area).
     half8 xr[24];
     const half_t* xrow = p.x + static_cast<size_t>(mc) * p.ldx + 8 * hi;
+    const unsigned xdump = lds_base + OFF_STAGE + wave * WAVE_AREA;
+    // scalar base + 32-bit lane offset: with 64-bit lane addresses hipcc keeps all of them (they do not depend
+    // on the third) from the first third to the last and spills them - every reload is an s_waitcnt vmcnt(0),
+    // i.e. a drained prefetch
+    // (a wave entirely behind the last pixel reads the last row: the lane offset is unsigned)
+    const int m0x = min(m0, p.M - 1);
+    const half_t* const xwave = p.x + static_cast<size_t>(m0x) * p.ldx;     // wave-uniform
+    const int xlast = p.M - 1 - m0x;                                         // last row of the picture, relative: >= 0
+    auto x_dma = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 4 * j + (lane >> 4);
+            const int chunk = (lane & 15) ^ (row & 15);
+            const unsigned off = static_cast<unsigned>(min(row, xlast) * p.ldx + 8 * chunk) * 2u;
+            lds_dma16_s(xwave + 128 * t, off, xdump + j * 1024);
+        }
+    };
+    auto x_read = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            xr[8 * t + i] = *reinterpret_cast<const half8*>(dump + px * 256 + (((2 * i + hi) ^ (px & 15)) << 4));
+    };
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            // the 8 loads of a third of x go out behind the k-steps 2, 3, 4: for the three steps that
-            // follow each of them they are younger than the slab the barrier certifies
             auto run = [&](auto have, auto next, auto extra) {
                 step_wide(g, (3 * ks + c) % NS, have, next, [&](int s) { return bf[ks * 4 + s]; },
                           *reinterpret_cast<float16v(*)[4]>(&acc2[4 * c]), no_piece, no_piece, std::integral_constant<int, 0>{}, extra);
             };
             using X0 = std::integral_constant<int, 0>;
             using X8 = std::integral_constant<int, 8>;
-            if (ks == 0 && c == 0) run(No{}, TagW{}, X0{});
-            else if (ks == 5 && c == 2) run(Yes{}, TagD{}, X8{});
-            else if (ks >= 3) run(Yes{}, TagW{}, X8{});
+            const int st = 3 * ks + c;
+            const bool x8 = (st >= 3 && st <= 5) || (st >= 8 && st <= 10) || (st >= 14 && st <= 16);
+            if (st == 0) run(No{}, TagW{}, X0{});
+            else if (st == 17) run(Yes{}, TagD{}, X0{});
+            else if (x8) run(Yes{}, TagW{}, X8{});
             else run(Yes{}, TagW{}, X0{});
             ++g;
-        }
-        if (ks >= 2 && ks <= 4) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xr[8 * (ks - 2) + i] = *reinterpret_cast<const half8*>(xrow + 128 * (ks - 2) + 16 * i);
+            if (st == 2) x_dma(0);
+            if (st == 7) x_dma(1);
+            if (st == 13) x_dma(2);
+            if (st == 6) x_read(0);
+            if (st == 12) x_read(1);
         }
     }
+    x_read(2);
     stamp();                                         // 1: dc.3 slabs done
 #pragma unroll
     for (int nt = 0; nt < 12; ++nt)
@@ -724,7 +801,7 @@ dcb_core_kernel(const CoreParams p)
                 runs_of(acc2[4 * c + nt], pr, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(bf[i][e]);
-                if (p.shortcut) {
+                if (p.shortcut & 1) {
                     const half8 r8 = *reinterpret_cast<const half8*>(xrow + 16 * i);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
@@ -754,39 +831,43 @@ dcb_core_kernel(const CoreParams p)
         half8 o4[4];
         // epilogue run r (tile r>>1, half r&1) of the parked pair, in the same three stages as the ffn.0 pieces
         // (read | index + gather | polynomial, one slice apart); dc0_flush: the pair's 64 channels go out
+        // (4 values at a time: with all 8 table entries of a run in flight the 56 registers of state pushed address
+        // registers of the slab walk into scratch, and every reload is an s_waitcnt vmcnt(0) = a drained prefetch)
         float4v dlo, dhi;
-        float dv[8], df[8];
-        float4 dc[8];
+        float dv[8], df[4];
+        float4 dc[4];
         auto dc0_read = [&](int r) {
             // run r = (tile r>>1, half r&1): parked units 2 (r&1) and 2 (r&1) + 1 of that tile, half-waves paired
             dlo = parked((r >> 1) * 4 + 2 * (r & 1));
             dhi = parked((r >> 1) * 4 + 2 * (r & 1) + 1);
         };
-        auto dc0_index = [&]() {
+        auto dc0_pair_up = [&]() {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dlo[e]), __float_as_uint(dhi[e]), false, false);
                 dv[e] = __uint_as_float(sw[0]);
                 dv[4 + e] = __uint_as_float(sw[1]);
             }
+        };
+        auto dc0_index = [&](int h) {          // table entries of values 4h .. 4h+3
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = fmaf(dv[e], 16.0f, 128.0f);
+            for (int e = 0; e < 4; ++e) {
+                float t = fmaf(dv[4 * h + e], 16.0f, 128.0f);
                 t = fminf(fmaxf(t, 0.0f), 255.99998f);
                 df[e] = __builtin_amdgcn_fractf(t);
                 dc[e] = tab[static_cast<int>(t) * R];
             }
         };
-        auto dc0_poly = [&](int r) {
-            half8 o;
+        half8 orun;
+        auto dc0_poly = [&](int r, int h) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 float pp = fmaf(dc[e].w, df[e], dc[e].z);
                 pp = fmaf(pp, df[e], dc[e].y);
                 pp = fmaf(pp, df[e], dc[e].x);
-                o[e] = to_half(dv[e] * pp);
+                orun[4 * h + e] = to_half(dv[4 * h + e] * pp);
             }
-            o4[r] = o;
+            if (h == 1) o4[r] = orun;
         };
         auto dc0_flush = [&](int first) { flush(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first); };
         // `stores`: row stores (negative count, see step_top) younger than the slabs the first steps certify - the
@@ -800,15 +881,23 @@ dcb_core_kernel(const CoreParams p)
                 auto body = [&](auto have, auto stores) {
                     step_deep(g, g % NS, have, TagD{}, [&](int s) { return bf[8 * k3 + s]; }, cur,
                               [&](int s) {
-                                  const int slot24 = 8 * k3 + s;            // run r: read in slice 5r+1, index in 5r+2, polynomial in 5r+3
-                                  if (with_prev && slot24 % 5 == 1 && slot24 < 20) dc0_read(slot24 / 5);
+                                  const int slot24 = 8 * k3 + s;            // run r: read in slice 5r, then one stage per slice
+                                  if (with_prev && slot24 % 5 == 0 && slot24 < 20) dc0_read(slot24 / 5);
                               },
                               [&](int s) {
-                                  const int slot24 = 8 * k3 + s;
-                                  if (with_prev && slot24 % 5 == 2 && slot24 < 20) dc0_index();
-                                  if (with_prev && slot24 % 5 == 3 && slot24 < 20) dc0_poly(slot24 / 5);
-                                  if (with_prev && slot24 == 22) dc0_flush(64 * (j - 1));
-                              }, std::integral_constant<int, 10>{}, stores);
+                                  const int slot24 = 8 * k3 + s, r = slot24 / 5, ph = slot24 % 5;
+                                  if (with_prev && slot24 < 20) {
+                                      if (ph == 1) { dc0_pair_up(); dc0_index(0); }
+                                      if (ph == 2) dc0_poly(r, 0);
+                                      if (ph == 3) dc0_index(1);
+                                      if (ph == 4) dc0_poly(r, 1);
+                                  }
+                                  if (with_prev && slot24 == 22) {
+                                      if (TIMELINE && g == G_CORE + 5) flush_probe = 6;       // pair 1: g is a constant there
+                                      dc0_flush(64 * (j - 1));
+                                      flush_probe = -1;
+                                  }
+                              }, std::integral_constant<int, 11>{}, stores);
                 };
                 if (k3 == 0) body(have_head, st0);
                 else if (k3 == 1) body(Yes{}, st1);
@@ -826,14 +915,23 @@ dcb_core_kernel(const CoreParams p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dc0_read(r);
-            dc0_index();
-            dc0_poly(r);
+            dc0_pair_up();
+            dc0_index(0);
+            dc0_poly(r, 0);
+            dc0_index(1);
+            dc0_poly(r, 1);
         }
         dc0_flush(64 * 5);
     }
     // the prefetches behind the last slab are still on their way into this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp();                                         // 11: end
+    if constexpr (TIMELINE) {
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) p.timeline[static_cast<size_t>(blockIdx.x) * 64 + 16 + i] = static_cast<long long>(fine_t[i]);
+        }
+    }
 }
 
 long long* g_core_timeline = nullptr;
@@ -867,6 +965,7 @@ void dcb_core(const DcbCoreDesc& d, hipStream_t stream)
     p.q = d.q; p.q2 = d.q2; p.w1n = d.w1n; p.b1n = d.b1n; p.t1n = d.t1n; p.ldt1 = d.ldt1;
     p.wsilu = wsilu_table_device();
     p.y = d.y; p.ldy = d.ldy; p.M = d.pixels; p.shortcut = d.shortcut ? 1 : 0;
+    if (g_core_timeline != nullptr && getenv("DCVC_CORE_NOSTORE") != nullptr) p.shortcut |= 2;
     p.timeline = g_core_timeline;
     static std::once_flag once;
     std::call_once(once, [] {

@@ -164,9 +164,21 @@ def test_corrupt_stream_does_not_crash():
     bad = bytearray(r["bit_stream"])
     for i in range(8, len(bad), 7):
         bad[i] ^= 0x5a
-    d = dec.decompress(bytes(bad[:len(bad) // 2]), {"height": 64, "width": 64}, 20, r["ec_parallel"], 0)
+    # a damaged stream either decodes to garbage pictures or is rejected with a clean error (an escape code no
+    # int8 symbol can have) - never a crash, a hang or an out-of-bounds read; the codec object stays usable
+    from dcvc_amd._lib import DcvcError
+    try:
+        d = dec.decompress(bytes(bad[:len(bad) // 2]), {"height": 64, "width": 64}, 20, r["ec_parallel"], 0)
+        torch.cuda.synchronize()
+        assert torch.isfinite(d["x_hat"].float()).all()
+    except DcvcError as e:
+        assert "corrupt" in str(e)
+    dec2 = _gpu_net(m)
+    dec2.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+    dec.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+    good = [g.decompress(r["bit_stream"], {"height": 64, "width": 64}, 20, r["ec_parallel"], 0)["x_hat"].clone() for g in (dec, dec2)]
     torch.cuda.synchronize()
-    assert torch.isfinite(d["x_hat"].float()).all()
+    assert torch.equal(good[0], good[1])
 
 
 def test_gop_hand_off_continues_bit_exactly():

@@ -70,11 +70,21 @@ def main():
     names = ["first slab landed", "dc.3 (18 slabs)", "y1 epilogue", "ffn super-chunk 0 (12 slabs)"] + \
             ["ffn super-chunk %d (15 slabs)" % i for i in range(1, 6)] + \
             ["last pair epilogue + ffn.2 (3 slabs)", "y epilogue + stores", "next dc.0 (18 slabs) + drain"]
+    fine = s[:, 16:40]
     s = s[:, :12]
     d = np.diff(s, axis=1)
     for i in range(d.shape[1]):
         print("   %-40s %7.0f cycles  (p90 %7.0f)" % (names[i + 1] if i + 1 < len(names) else "?", np.median(d[:, i]), np.percentile(d[:, i], 90)))
     print("   total %.0f cycles" % np.median(s[:, 11] - s[:, 0]))
+    if fine.any():
+        labels = ["wait + barrier + plan", "slice 0", "slice 1", "slice 2", "slice 3"]
+        f = np.diff(fine[:, 6:12], axis=1) % (1 << 32)
+        print("   the flush of that step: 4 ds_write %4.0f | wait %4.0f | 4 ds_read issue %4.0f | waits + stores %4.0f | final wait %4.0f"
+              % tuple(np.median(f[:, i]) for i in range(5)))
+        for name, base in (("dc.3 slab 7", 0), ("next dc.0, pair 1, k-third 2 (flush; slices in twos)", 18)):
+            f = np.diff(fine[:, base:base + 6], axis=1) % (1 << 32)
+            print("   %-38s %s   = %d" % (name, "  ".join("%s %4.0f" % (l, np.median(f[:, i])) for i, l in enumerate(labels)),
+                                           np.median((fine[:, base + 5] - fine[:, base]) % (1 << 32))))
 
 if __name__ == "__main__":
     main()
