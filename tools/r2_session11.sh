@@ -10,7 +10,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/s11_prof -o s11 --
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/s11_fetch -o f -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/s11_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/s11_write -o w -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/s11_write.log 2>&1
 cd $R
-python tools/hbm_traffic.py gpurun_out/s11_fetch gpurun_out/s11_write gpurun_out/r02_hbm_traffic_final.json $(cat .git_head 2>/dev/null || echo final) | tail -24
+python tools/hbm_traffic.py gpurun_out/s11_fetch gpurun_out/s11_write gpurun_out/r02_hbm_traffic_final.json ${DCVC_COMMIT:-final} | tail -24
 python tools/rocpd_stats.py $(find gpurun_out/s11_prof -name "*.db" | head -1) gpurun_out/r02_bench_kernel_stats_final.csv | head -16 | cut -c1-150
 find gpurun_out/s11_fetch gpurun_out/s11_write -name "*.csv" -size +3M -delete
 rm -rf gpurun_out/s11_prof
