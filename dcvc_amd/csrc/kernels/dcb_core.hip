@@ -51,9 +51,14 @@ constexpr int LPS = SLAB / (NTHREADS * 16);   // global_load_lds per thread and 
 constexpr int R = 4;                     // interleaved copies of the WSiLU table
 constexpr int TABLE_BYTES = WSILU_SEGMENTS * 16;
 constexpr int OFF_TABLE = NS * SLAB;
-constexpr int OFF_CONST = OFF_TABLE + R * TABLE_BYTES;    // b3 | b0 | b2 | b1n | q | q2, fp16
-constexpr int CONST_HALVES = C + 4 * C + C + C + C + C;
-constexpr int OFF_SLABS = OFF_CONST + CONST_HALVES * 2;    // weight stream: address | shape of every slab, 8 B each
+// constants: the biases b3 | b0 | b2 | b1n as FP32 (an accumulator tile is initialised by four 16-byte LDS reads
+// straight into the accumulator registers: as fp16 it took 16 conversions + 16 v_accvgpr_write per tile, 2.25 VALU
+// operations per ffn.0 output element - a sixth of the walk's VALU work), then q | q2 as fp16
+constexpr int CONST_HALVES = C + 4 * C + C + C + C + C;    // 16-byte units are fetched as fp16
+constexpr int BIAS_FLOATS = 7 * C;
+constexpr int OFF_CONST = OFF_TABLE + R * TABLE_BYTES;
+constexpr int OFF_QSCALE = OFF_CONST + BIAS_FLOATS * 4;    // q | q2, fp16
+constexpr int OFF_SLABS = OFF_QSCALE + 2 * C * 2;          // weight stream: address | shape of every slab, 8 B each
 constexpr int SLAB_ENTRIES = 136;
 constexpr int OFF_STAGE = OFF_SLABS + SLAB_ENTRIES * 8;
 // per wave: [finished accumulator pair, 32 floats per lane, lane-linear 16-B units: 8 KB][64-channel output rows]
@@ -289,7 +294,8 @@ dcb_core_kernel(const CoreParams p)
     }
 
     const float4* tab = reinterpret_cast<const float4*>(smem + OFF_TABLE) + (lane & (R - 1));
-    half_t* lconst = reinterpret_cast<half_t*>(smem + OFF_CONST);
+    float* lbias = reinterpret_cast<float*>(smem + OFF_CONST);
+    half_t* lqs = reinterpret_cast<half_t*>(smem + OFF_QSCALE);
     {
         float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
 #pragma unroll
@@ -297,15 +303,26 @@ dcb_core_kernel(const CoreParams p)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int u = tid + k * NTHREADS;
-            if (u < CONST_UNITS) *reinterpret_cast<half8*>(lconst + u * 8) = constv[k];
+            if (u < BIAS_FLOATS / 8) {
+                float4v lo4, hi4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo4[e] = static_cast<float>(constv[k][e]);
+                    hi4[e] = static_cast<float>(constv[k][4 + e]);
+                }
+                *reinterpret_cast<float4v*>(lbias + u * 8) = lo4;
+                *reinterpret_cast<float4v*>(lbias + u * 8 + 4) = hi4;
+            } else if (u < CONST_UNITS) {
+                *reinterpret_cast<half8*>(lqs + (u - BIAS_FLOATS / 8) * 8) = constv[k];
+            }
         }
     }
-    const half_t* lb3 = lconst;
-    const half_t* lb0 = lconst + C;
-    const half_t* lb2 = lconst + 5 * C;
-    const half_t* lb1n = lconst + 6 * C;
-    const half_t* lq = lconst + 7 * C;
-    const half_t* lq2 = lconst + 8 * C;
+    const float* lb3 = lbias;
+    const float* lb0 = lbias + C;
+    const float* lb2 = lbias + 5 * C;
+    const float* lb1n = lbias + 6 * C;
+    const half_t* lq = lqs;
+    const half_t* lq2 = lqs + C;
     int stamp_no = 0;
     auto stamp = [&]() {
         if (TIMELINE && tid == 0 && stamp_no < 64) {
@@ -487,13 +504,13 @@ dcb_core_kernel(const CoreParams p)
 
     // accumulator tile (32 channels from `first`) initialised with the bias:
     // acc[r] = channel first + 8 (r>>2) + 4 hi + (r&3)
-    auto bias_tile = [&](float16v& acc, const half_t* bias, int first) {
-        const half_t* bp = bias + first + 4 * hi;
+    auto bias_tile = [&](float16v& acc, const float* bias, int first) {
+        const float* bp = bias + first + 4 * hi;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const half4 b4 = *reinterpret_cast<const half4*>(bp + 8 * g4);
+            const float4v b4 = *reinterpret_cast<const float4v*>(bp + 8 * g4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[4 * g4 + e] = static_cast<float>(b4[e]);
+            for (int e = 0; e < 4; ++e) acc[4 * g4 + e] = b4[e];
         }
     };
     // accumulator tile -> the two 8-channel runs this lane owns after pairing the half-waves:
@@ -682,6 +699,8 @@ dcb_core_kernel(const CoreParams p)
             ec[q & 1][e] = tab[static_cast<int>(t) * R];
         }
     };
+    // (tried: the two operations with paired operands - t = 16 v + 128 and v * p - as packed fp32; hipcc pairs up only
+    // half of them and pays for it in v_mov / s_nop: 1 538 instead of 1 400 VALU per super-chunk)
     auto piece_poly = [&](int q) {
         float v[4];
 #pragma unroll
