@@ -377,12 +377,17 @@ dcb_core_kernel(const CoreParams p)
     // A NEGATIVE `extra` = that many global STORES (gfx950 counts stores in vmcnt too): a row store is skipped
     // when none of its rows exists, so only a wave whose 32 pixels are all inside the picture may count on them.
     const bool wave_full = m0 + 32 <= p.M;
+#ifdef DCB_CORE_STAGED_STORES
+    const bool wave_counts_stores = wave_full;
+#else
+    const bool wave_counts_stores = m0 < p.M;       // direct row stores: issued by every wave that owns a pixel
+#endif
     auto step_top = [&](int g, int slot, auto extra) {
         constexpr int ex = decltype(extra)::value;
         if constexpr (ex >= 0) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS + ex) : "memory");
         } else {
-            if (wave_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS - ex) : "memory");
+            if (wave_counts_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS - ex) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -575,6 +580,23 @@ dcb_core_kernel(const CoreParams p)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (TIMELINE && flush_probe >= 0) fine(flush_probe + 5);
     };
+
+    // The same rows WITHOUT the LDS round trip: every lane stores its own 16-byte runs (32 B per pixel row and
+    // instruction, the four / eight runs of a row complete a 128-B line in L2). One instruction per run, issued by
+    // every wave that owns at least one pixel.
+    auto store_runs = [&](const half8* o, auto nch_tag, half_t* dst, int ld, int first) {
+        constexpr int NCH = decltype(nch_tag)::value;
+        if (m0 + px < p.M && !(TIMELINE && (p.shortcut & 2))) {     // (DCVC_CORE_NOSTORE: timing experiment)
+            half_t* const row = dst + static_cast<size_t>(m0 + px) * ld + first + 8 * hi;
+#pragma unroll
+            for (int i = 0; i < NCH / 16; ++i) store_line(row + 16 * i, o[i]);
+        }
+    };
+#ifdef DCB_CORE_STAGED_STORES
+#define EMIT_ROWS flush
+#else
+#define EMIT_ROWS store_runs
+#endif
 
     int g = 0;
     // ================================================================ dc.3: y1 = W3 t2 + b3' + x
@@ -845,7 +867,7 @@ dcb_core_kernel(const CoreParams p)
                 bf[i] = o;
                 o8[2 * nt + pr] = o;
             }
-        flush(o8, std::integral_constant<int, 128>{}, p.y, p.ldy, 128 * c);
+        EMIT_ROWS(o8, std::integral_constant<int, 128>{}, p.y, p.ldy, 128 * c);
     }
 
     stamp();                                         // 10: y written
@@ -892,7 +914,7 @@ dcb_core_kernel(const CoreParams p)
             }
             if (h == 1) o4[r] = orun;
         };
-        auto dc0_flush = [&](int first) { flush(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first); };
+        auto dc0_flush = [&](int first) { EMIT_ROWS(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first); };
         // `stores`: row stores (negative count, see step_top) younger than the slabs the first steps certify - the
         // flush of the previous pair sits behind 3 of the 4 prefetch pieces of the step before, the y epilogue
         // behind all of them
@@ -915,11 +937,11 @@ dcb_core_kernel(const CoreParams p)
                                       if (ph == 3) dc0_index(1);
                                       if (ph == 4) dc0_poly(r, 1);
                                   }
-                                  if (with_prev && slot24 == 22) {
-                                      if (TIMELINE && g == G_CORE + 5) flush_probe = 6;       // pair 1: g is a constant there
-                                      dc0_flush(64 * (j - 1));
-                                      flush_probe = -1;
-                                  }
+                                  // the 64 channels finished during the PREVIOUS pair go out right behind this step's
+                                  // counted wait, when the fewest loads are in flight: with 11 LDS-DMA pieces outstanding
+                                  // (slice 6 of the third step, where they used to sit) each row store took ~200 cycles
+                                  // to issue, 830 per pair (measured with the stores compiled out)
+                                  if (j >= 2 && slot24 == 0) dc0_flush(64 * (j - 2));
                               }, std::integral_constant<int, 11>{}, stores);
                 };
                 if (k3 == 0) body(have_head, st0);
@@ -934,7 +956,8 @@ dcb_core_kernel(const CoreParams p)
         using S24 = std::integral_constant<int, -24>;        // the y epilogue = 3 x 8
         dc0_pair(0, No{}, false, S24{}, S24{}, S24{});
         dc0_pair(1, Yes{}, true, S0{}, S0{}, S0{});
-        for (int j = 2; j < 6; ++j) dc0_pair(j, Yes{}, true, S4{}, S4{}, S0{});
+        for (int j = 2; j < 6; ++j) dc0_pair(j, Yes{}, true, S0{}, S4{}, S4{});     // stores in slice 0 of the first step
+        dc0_flush(64 * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dc0_read(r);
