@@ -98,11 +98,15 @@ inline uint32_t dec_byte(DecState& s)
 
 inline uint32_t dec_bits(DecState& s)
 {
+    // one 2-bit bypass group; the refill (one byte every fourth group of a run) is a select, not a branch: the
+    // escape-coded symbols of the low-qp streams take 5-8 groups each, and a quarter of those branches mispredict
     const uint32_t val = s.r & kBypassMax;
-    s.r >>= kBypassBits;
-    if (s.r < kRansLow) {
-        s.r = (s.r << 8) | dec_byte(s);
-    }
+    const uint32_t r = s.r >> kBypassBits;
+    const bool more = s.p != s.end;                       // a well-formed stream never runs dry
+    const uint32_t byte = more ? *s.p : 0u;
+    const uint32_t need = static_cast<uint32_t>(r < kRansLow);
+    s.r = need ? ((r << 8) | byte) : r;
+    s.p += need & static_cast<uint32_t>(more);
     return val;
 }
 

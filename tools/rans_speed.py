@@ -16,6 +16,7 @@ import MLCodec_extensions_cpp as ec  # noqa: E402
 
 def main():
     n_per_step = int(sys.argv[1]) if len(sys.argv) > 1 else 250_000
+    spread = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0        # > 1: escape-coded symbols (the low-qp streams)
     net = models.DMCI()
     net.load_state_dict(synthetic.synthetic_state_dict(arch.dmci_spec(), 0))
     net.update(0.15)
@@ -25,7 +26,7 @@ def main():
     for _ in range(4):
         idx = rng.integers(8, 100, n_per_step)
         scale = np.exp(-2.2073 + idx * (2.7726 + 2.2073) / 127)
-        sym = np.clip(np.rint(rng.standard_normal(n_per_step) * scale), -127, 127).astype(np.int64)
+        sym = np.clip(np.rint(rng.standard_normal(n_per_step) * scale * spread), -127, 127).astype(np.int64)
         steps.append((((sym << 8) + idx).astype(np.int16), idx.astype(np.uint8)))
     for par in (1, 8):
         e = ec.RansEncoder()
