@@ -63,6 +63,35 @@ def write_dcvw(path, kind, net, skip_thres):
     return len(sd)
 
 
+def read_dcvw(path):
+    """-> (kind name, skip_thres, {name: numpy array}) - the inverse of write_dcvw (tests, inspection)"""
+    names = {v: k for k, v in KINDS.items()}
+    dtypes = {0: np.float16, 1: np.float32, 2: np.int32}
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] != b"DCVW1\0\0\0":
+        raise ValueError("not a .dcvw file")
+    kind, skip_thres, count = struct.unpack_from("<IfI", data, 8)
+    pos, out = 20, {}
+    for _ in range(count):
+        start = pos
+        (nlen,) = struct.unpack_from("<H", data, pos)
+        name = data[pos + 2:pos + 2 + nlen].decode()
+        pos += 2 + nlen
+        code, ndim = struct.unpack_from("<BB", data, pos)
+        pos += 2
+        dims = struct.unpack_from("<%dq" % ndim, data, pos)
+        pos += 8 * ndim
+        (nbytes,) = struct.unpack_from("<Q", data, pos)
+        pos += 8
+        out[name] = np.frombuffer(data, dtype=dtypes[code], count=nbytes // np.dtype(dtypes[code]).itemsize, offset=pos).reshape(dims)
+        pos += nbytes
+        pos += (-(pos - start)) % 8
+    if pos != len(data):
+        raise ValueError("trailing bytes in .dcvw file")
+    return names[kind], skip_thres, out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--model", required=True, choices=tuple(KINDS))

@@ -56,3 +56,22 @@ def test_picture_io_oracle_equals_reference_ops(golden):
     r = frame_io.x_to_yuv420(golden["x_hat"], h, w)
     for k in ("y16", "uv16", "y8", "uv8"):
         assert np.array_equal(r[k], golden[k]), k
+
+
+def test_weight_file_round_trip(tmp_path):
+    """.dcvw (the native tool's weight file, dcvc_amd/export_weights.py): every tensor set_param() receives - the fp16
+    state_dict and the four int32 entropy tables - comes back bit for bit, records are 8-byte aligned."""
+    from codec_util import dmc_ld_model
+    from dcvc_amd import export_weights
+    m = dmc_ld_model(skip_thres=0.15)
+    path = str(tmp_path / "ld.dcvw")
+    n = export_weights.write_dcvw(path, "ld", m, 0.15)
+    kind, thres, tensors = export_weights.read_dcvw(path)
+    assert kind == "ld" and abs(thres - 0.15) < 1e-7 and len(tensors) == n
+    sd = m.add_cdf_to_state_dict(m.state_dict())
+    assert set(tensors) == set(sd)
+    for name, t in sd.items():
+        a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+        want = a.astype(np.float16) if a.dtype.kind == "f" else a
+        assert tensors[name].dtype == want.dtype and np.array_equal(tensors[name], want), name
+    assert tensors["gaussian_encoder.quantized_cdf"].dtype == np.int32
