@@ -262,10 +262,11 @@ def cpu_baseline(cpu_net):
     cores = os.cpu_count() or 1
     sd = cpu_net.state_dict()
     full = HEIGHT * WIDTH
-    # thread count: the fastest of {all, 64, 32, 16} on a 512x512 crop (oversubscribing a 2-socket host with one
-    # small convolution per op is slower than one thread), then one padded 1080p picture (1088x1920) with it;
-    # one thread: a 256x256 crop, scaled by area
-    tried = {t: torch_graph.time_forward(sd, 512, 512, 32, t) for t in sorted({min(cores, c) for c in (cores, 64, 32, 16)})}
+    # thread count: the fastest of {64, 32, 16} on a 512x512 crop, then one padded 1080p picture (1088x1920) with it.
+    # (All 256 hardware threads of the GPU box were measured once: 114 s for the CROP - one small convolution per op
+    # oversubscribes a 2-socket host hopelessly - so that trial is not repeated in every run.) One thread: a 256x256
+    # crop, scaled by area
+    tried = {t: torch_graph.time_forward(sd, 512, 512, 32, t) for t in sorted({min(cores, c) for c in (64, 32, 16)})}
     best = min(tried, key=tried.get)
     t_all = torch_graph.time_forward(sd, 1088, 1920, 32, best)
     t_one = torch_graph.time_forward(sd, 256, 256, 32, 1) * (1088 * 1920) / (256 * 256)
@@ -281,8 +282,9 @@ def cpu_baseline(cpu_net):
         "value": 1.0 / t_all, "unit": "frames/s", "cores": best, "kind": "port",
         "sample": "fp32 PyTorch graph of the reference's CPU-runnable path (DMCI.forward_one_frame, image_model.py:150-171, "
                   "restated in oracle/torch_graph.py: encoder + priors + decoder of one 1088x1920 picture, no entropy coding) "
-                  "on %d of %d hardware threads (fastest of %s on a 512x512 crop): %.2f s per picture"
-                  % (best, cores, {t: round(v, 2) for t, v in tried.items()}, t_all),
+                  "on %d of %d hardware threads (fastest of %s on a 512x512 crop; all %d threads: 114 s for the crop, measured "
+                  "once): %.2f s per picture"
+                  % (best, cores, {t: round(v, 2) for t, v in tried.items()}, cores, t_all),
         "one_thread": {"value": 1.0 / t_one, "unit": "frames/s", "cores": 1,
                        "sample": "the same graph on 1 thread (the reference harness pins 1, common.py:270): one 256x256 crop, "
                                  "scaled by area to 1080p (%.1f s per picture)" % t_one},
