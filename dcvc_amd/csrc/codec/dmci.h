@@ -88,6 +88,7 @@ private:
     int16_t *m_SYM = nullptr, *m_COMP = nullptr;
     uint8_t *m_COND = nullptr, *m_IDX = nullptr, *m_CIDX = nullptr;
     int8_t* m_DECODED = nullptr;
+    size_t m_idx_region = 0;           // bytes per decode step in m_CIDX / m_h_idx: 16 (count) + symbols of a step
     int32_t *m_CNT = nullptr, *m_TOTALS = nullptr;
     // pinned host staging
     Pinned<int32_t> m_h_totals;

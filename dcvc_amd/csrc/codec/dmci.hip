@@ -106,14 +106,17 @@ void DmciCodec::prepare(int height, int width)
     m_COMP = static_cast<int16_t*>(m_bmem.alloc(4 * nq * 2));
     m_COND = static_cast<uint8_t*>(m_bmem.alloc(nq / 8 + 8));
     m_IDX = static_cast<uint8_t*>(m_bmem.alloc(nq));
-    m_CIDX = static_cast<uint8_t*>(m_bmem.alloc(4 * nq));
+    // decode side: step k's compacted indexes live in their own region [count, int32 | 12 B pad | indexes], so that
+    // ONE device->host copy brings the count and (nearly always) all the indexes of a step
+    m_idx_region = (16 + nq + 15) / 16 * 16;
+    m_CIDX = static_cast<uint8_t*>(m_bmem.alloc(4 * m_idx_region));
     m_DECODED = static_cast<int8_t*>(m_bmem.alloc(4 * nq));
     m_CNT = static_cast<int32_t*>(m_bmem.alloc(sizeof(int32_t) * symbol_blocks(static_cast<int>(nq))));
     m_TOTALS = static_cast<int32_t*>(m_bmem.alloc(sizeof(int32_t) * 4));
     m_h_totals.reserve(16);
     m_h_sym.reserve(4 * nq);
     m_h_z.reserve(P64 * kChZ + 64);
-    m_h_idx.reserve(4 * nq);
+    m_h_idx.reserve(4 * m_idx_region);
     m_h_dec.reserve(4 * nq);
 }
 
@@ -314,7 +317,8 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
         d.index = m_IDX; d.cond = m_COND; d.block_count = m_CNT;
         d.H = g.H16; d.W = g.W16; d.C = kChY; d.step = k; d.skip_thres = m_skip_thres;
         y_step_dec_index(d, st);
-        compact(m_IDX, 1, m_COND, m_CNT, nq, m_CIDX, m_TOTALS, k, st);
+        uint8_t* region = m_CIDX + static_cast<size_t>(k) * m_idx_region;
+        compact(m_IDX, 1, m_COND, m_CNT, nq, region + 16, reinterpret_cast<int32_t*>(region), 0, st);
     };
     run_stage(kDec0, st, [&] {
         int8_to_half(m_ZI8, m_ZH, nz, st);
@@ -322,29 +326,37 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
         index_step(0);
     });
     bind_stage_arg(kDec1 + 3, x_hat);
-    int base = 0;
+    // the first copy of a step takes the count and up to kFirst index bytes (a 1080p step has 50-130 k of its 522 k
+    // possible symbols): one copy + one synchronisation per step instead of two of each (the second pair cost
+    // ~25 us of GPU idle time per step in the kernel trace)
+    constexpr size_t kFirst = 192 * 1024;
     for (int k = 0; k < 4; ++k) {
         // one GPU -> CPU -> GPU round trip per autoregressive step (dmci_proxy.cpp:857-871)
         auto t_w = clk::now();
-        hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
+        const uint8_t* region = m_CIDX + static_cast<size_t>(k) * m_idx_region;
+        uint8_t* h_region = m_h_idx.get() + static_cast<size_t>(k) * m_idx_region;
+        const size_t first = std::min(m_idx_region, 16 + kFirst);
+        hip_check(hipMemcpyAsync(h_region, region, first, hipMemcpyDeviceToHost, st), "D2H count + indexes");
         hip_check(hipStreamSynchronize(st), "sync");
-        const int n = m_h_totals[k];
-        if (n > 0) {
-            hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX + base, n, hipMemcpyDeviceToHost, st), "D2H indexes");
+        const int n = *reinterpret_cast<const int32_t*>(h_region);
+        if (n < 0 || static_cast<size_t>(n) > nq) throw std::runtime_error("DMCI decompress: bad symbol count");
+        if (16 + static_cast<size_t>(n) > first) {
+            hip_check(hipMemcpyAsync(h_region + first, region + first, 16 + n - first, hipMemcpyDeviceToHost, st), "D2H indexes");
             hip_check(hipStreamSynchronize(st), "sync");
-            us_wait += us_since(t_w);
+        }
+        us_wait += us_since(t_w);
+        int8_t* h_dec = m_h_dec.get() + static_cast<size_t>(k) * nq;
+        if (n > 0) {
             auto t_r = clk::now();
-            m_dec.decode_y(m_h_idx.get(), n, m_h_dec.get() + base);
+            m_dec.decode_y(h_region + 16, n, h_dec);
             us_rans += us_since(t_r);
             n_sym += n;
-            hip_check(hipMemcpyAsync(m_DECODED + base, m_h_dec.get() + base, n, hipMemcpyHostToDevice, st), "H2D symbols");
-        } else {
-            us_wait += us_since(t_w);
+            hip_check(hipMemcpyAsync(m_DECODED + static_cast<size_t>(k) * nq, h_dec, n, hipMemcpyHostToDevice, st), "H2D symbols");
         }
-        base += n;
         run_stage(kDec1 + k, st, [&] {
             YStepDecRestore d;
-            d.decoded = m_DECODED; d.cond = m_COND; d.block_count = m_CNT; d.totals = m_TOTALS; d.slot = k;
+            d.decoded = m_DECODED + static_cast<size_t>(k) * nq; d.cond = m_COND; d.block_count = m_CNT;
+            d.totals = m_TOTALS; d.slot = 0;                   // the step's own region: no base to add up
             d.means = (k == 0 ? m_PARAMS : m_SP) + kChY; d.ldm = 2 * kChY;
             d.y_hat_acc = m_CAT; d.ldacc = 2 * kChY;
             d.H = g.H16; d.W = g.W16; d.C = kChY; d.step = k; d.first = (k == 0);
