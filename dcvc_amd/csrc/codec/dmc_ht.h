@@ -131,6 +131,8 @@ private:
     half_t* m_SP = nullptr;      // [P16][256] means (HT-S) / [P16][512] scales | means (HT-L)
     int16_t *m_SYM = nullptr, *m_COMP = nullptr;
     uint8_t *m_COND = nullptr, *m_IDX = nullptr, *m_CIDX = nullptr;
+    size_t m_idx_region = 0;          // bytes per decode round trip in m_CIDX / m_h_idx: 16 (count) + its symbols
+    static constexpr size_t kFirstIdxCopy = 192 * 1024;      // index bytes the first copy of a round trip takes along
     int8_t *m_DECODED = nullptr, *m_YQ = nullptr;
     int32_t *m_CNT = nullptr, *m_TOTALS = nullptr;
     Pinned<int32_t> m_h_totals;

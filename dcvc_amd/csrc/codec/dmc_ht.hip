@@ -129,7 +129,10 @@ void DmcHtCodec::prepare(int height, int width)
     m_COMP = static_cast<int16_t*>(m_bmem.alloc(n * 2));
     m_COND = static_cast<uint8_t*>(m_bmem.alloc(n / 8 + 8));
     m_IDX = static_cast<uint8_t*>(m_bmem.alloc(n));
-    m_CIDX = static_cast<uint8_t*>(m_bmem.alloc(n));
+    // decode side: [count, int32 | 12 B pad | compacted indexes] per round trip (HT-S: one of n symbols, HT-L: four
+    // of n / 4), so that ONE device->host copy brings the count and (nearly always) all the indexes
+    m_idx_region = (16 + (m_hts ? n : n / 4) + 15) / 16 * 16;
+    m_CIDX = static_cast<uint8_t*>(m_bmem.alloc((m_hts ? 1 : 4) * m_idx_region));
     m_DECODED = static_cast<int8_t*>(m_bmem.alloc(n));
     m_YQ = static_cast<int8_t*>(m_bmem.alloc(n));
     m_CNT = static_cast<int32_t*>(m_bmem.alloc(sizeof(int32_t) * symbol_blocks(static_cast<int>(n))));
@@ -137,7 +140,7 @@ void DmcHtCodec::prepare(int height, int width)
     m_h_totals.reserve(16);
     m_h_sym.reserve(n);
     m_h_z.reserve(P64 * kChZ + 64);
-    m_h_idx.reserve(n);
+    m_h_idx.reserve((m_hts ? 1 : 4) * m_idx_region);
     m_h_dec.reserve(n);
 }
 
@@ -456,23 +459,26 @@ void DmcHtCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
             d.index = m_IDX; d.cond = m_COND; d.block_count = m_CNT;
             d.H = g.H16; d.W = g.W16; d.C = kChY; d.skip_thres = m_skip_thres;
             mask_dec_index(d, st);
-            compact(m_IDX, 1, m_COND, m_CNT, ny, m_CIDX, m_TOTALS, 0, st);
+            compact(m_IDX, 1, m_COND, m_CNT, ny, m_CIDX + 16, reinterpret_cast<int32_t*>(m_CIDX), 0, st);
         });
-        hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
-        hip_check(hipStreamSynchronize(st), "sync");
-        const int n = m_h_totals[0];
-        if (n > 0) {
-            hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX, n, hipMemcpyDeviceToHost, st), "D2H indexes");
-            hip_check(hipEventRecord(m_ev_idx, st), "hipEventRecord");
-        }
+        // count + the first kFirst index bytes in one copy, no synchronisation in front of the context network
+        const size_t first = std::min(m_idx_region, 16 + kFirstIdxCopy);
+        hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX, first, hipMemcpyDeviceToHost, st), "D2H count + indexes");
+        hip_check(hipEventRecord(m_ev_idx, st), "hipEventRecord");
         // context network + the y-independent reduction run while the host decodes y
         run_stage(kDec2, st, [&] {
             run_fe(st);
             run_reduction(st);
         });
+        hip_check(hipEventSynchronize(m_ev_idx), "hipEventSynchronize");
+        const int n = *reinterpret_cast<const int32_t*>(m_h_idx.get());
+        if (n < 0 || n > ny) throw std::runtime_error("DMC-HT decompress: bad symbol count");
+        if (16 + static_cast<size_t>(n) > first) {
+            hip_check(hipMemcpyAsync(m_h_idx.get() + first, m_CIDX + first, 16 + n - first, hipMemcpyDeviceToHost, st), "D2H indexes");
+            hip_check(hipStreamSynchronize(st), "sync");
+        }
         if (n > 0) {
-            hip_check(hipEventSynchronize(m_ev_idx), "hipEventSynchronize");
-            m_dec.decode_y(m_h_idx.get(), n, m_h_dec.get());
+            m_dec.decode_y(m_h_idx.get() + 16, n, m_h_dec.get());
             hip_check(hipMemcpyAsync(m_DECODED, m_h_dec.get(), n, hipMemcpyHostToDevice, st), "H2D symbols");
         }
         run_stage(kDecStep + 3, st, [&] {
@@ -499,7 +505,8 @@ void DmcHtCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
             d.index = m_IDX; d.cond = m_COND; d.block_count = m_CNT;
             d.H = g.H16; d.W = g.W16; d.C = kChY; d.step = k; d.skip_thres = m_skip_thres;
             y_step_dec_index(d, st);
-            compact(m_IDX, 1, m_COND, m_CNT, nq, m_CIDX, m_TOTALS, k, st);
+            uint8_t* region = m_CIDX + static_cast<size_t>(k) * m_idx_region;
+            compact(m_IDX, 1, m_COND, m_CNT, nq, region + 16, reinterpret_cast<int32_t*>(region), 0, st);
         };
         run_stage(kDec1, st, [&] {
             int8_to_half(m_ZI8, m_ZH, nz, st);
@@ -508,21 +515,26 @@ void DmcHtCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
             run_fe(st);
             index_step(0);
         });
-        int base = 0;
         for (int k = 0; k < 4; ++k) {
-            hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
+            const uint8_t* region = m_CIDX + static_cast<size_t>(k) * m_idx_region;
+            uint8_t* h_region = m_h_idx.get() + static_cast<size_t>(k) * m_idx_region;
+            const size_t first = std::min(m_idx_region, 16 + kFirstIdxCopy);
+            hip_check(hipMemcpyAsync(h_region, region, first, hipMemcpyDeviceToHost, st), "D2H count + indexes");
             hip_check(hipStreamSynchronize(st), "sync");
-            const int n = m_h_totals[k];
-            if (n > 0) {
-                hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX + base, n, hipMemcpyDeviceToHost, st), "D2H indexes");
+            const int n = *reinterpret_cast<const int32_t*>(h_region);
+            if (n < 0 || n > nq) throw std::runtime_error("DMC-HT decompress: bad symbol count");
+            if (16 + static_cast<size_t>(n) > first) {
+                hip_check(hipMemcpyAsync(h_region + first, region + first, 16 + n - first, hipMemcpyDeviceToHost, st), "D2H indexes");
                 hip_check(hipStreamSynchronize(st), "sync");
-                m_dec.decode_y(m_h_idx.get(), n, m_h_dec.get() + base);
-                hip_check(hipMemcpyAsync(m_DECODED + base, m_h_dec.get() + base, n, hipMemcpyHostToDevice, st), "H2D symbols");
             }
-            base += n;
+            int8_t* h_dec = m_h_dec.get() + static_cast<size_t>(k) * nq;
+            if (n > 0) {
+                m_dec.decode_y(h_region + 16, n, h_dec);
+                hip_check(hipMemcpyAsync(m_DECODED + static_cast<size_t>(k) * nq, h_dec, n, hipMemcpyHostToDevice, st), "H2D symbols");
+            }
             run_stage(kDecStep + k, st, [&] {
                 YStepDecRestore d;
-                d.decoded = m_DECODED; d.cond = m_COND; d.block_count = m_CNT; d.totals = m_TOTALS; d.slot = k;
+                d.decoded = m_DECODED + static_cast<size_t>(k) * nq; d.cond = m_COND; d.block_count = m_CNT; d.totals = m_TOTALS; d.slot = 0;
                 if (k == 0) { d.means = m_COMMON + 2 * kChY; d.ldm = ldc; }
                 else { d.means = m_SP + kChY; d.ldm = 2 * kChY; }
                 d.y_hat_acc = m_CATSP; d.ldacc = 2 * kChY;
