@@ -459,26 +459,26 @@ void DmcHtCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
             d.index = m_IDX; d.cond = m_COND; d.block_count = m_CNT;
             d.H = g.H16; d.W = g.W16; d.C = kChY; d.skip_thres = m_skip_thres;
             mask_dec_index(d, st);
-            compact(m_IDX, 1, m_COND, m_CNT, ny, m_CIDX + 16, reinterpret_cast<int32_t*>(m_CIDX), 0, st);
+            compact(m_IDX, 1, m_COND, m_CNT, ny, m_CIDX, m_TOTALS, 0, st);
         });
-        // count + the first kFirst index bytes in one copy, no synchronisation in front of the context network
-        const size_t first = std::min(m_idx_region, 16 + kFirstIdxCopy);
-        hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX, first, hipMemcpyDeviceToHost, st), "D2H count + indexes");
-        hip_check(hipEventRecord(m_ev_idx, st), "hipEventRecord");
+        // (one copy for count + indexes in front of the context network was measured SLOWER here - LD 300 -> 271,
+        // HT-S 570 -> 541 pictures/s: the 192 KB copy sits in the stream in front of the context network's
+        // kernels; the two small copies with a synchronisation in between do not hold them up)
+        hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
+        hip_check(hipStreamSynchronize(st), "sync");
+        const int n = m_h_totals[0];
+        if (n > 0) {
+            hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX, n, hipMemcpyDeviceToHost, st), "D2H indexes");
+            hip_check(hipEventRecord(m_ev_idx, st), "hipEventRecord");
+        }
         // context network + the y-independent reduction run while the host decodes y
         run_stage(kDec2, st, [&] {
             run_fe(st);
             run_reduction(st);
         });
-        hip_check(hipEventSynchronize(m_ev_idx), "hipEventSynchronize");
-        const int n = *reinterpret_cast<const int32_t*>(m_h_idx.get());
-        if (n < 0 || n > ny) throw std::runtime_error("DMC-HT decompress: bad symbol count");
-        if (16 + static_cast<size_t>(n) > first) {
-            hip_check(hipMemcpyAsync(m_h_idx.get() + first, m_CIDX + first, 16 + n - first, hipMemcpyDeviceToHost, st), "D2H indexes");
-            hip_check(hipStreamSynchronize(st), "sync");
-        }
         if (n > 0) {
-            m_dec.decode_y(m_h_idx.get() + 16, n, m_h_dec.get());
+            hip_check(hipEventSynchronize(m_ev_idx), "hipEventSynchronize");
+            m_dec.decode_y(m_h_idx.get(), n, m_h_dec.get());
             hip_check(hipMemcpyAsync(m_DECODED, m_h_dec.get(), n, hipMemcpyHostToDevice, st), "H2D symbols");
         }
         run_stage(kDecStep + 3, st, [&] {

@@ -111,7 +111,6 @@ private:
     half_t* m_MEANS1 = nullptr;  // [P16][128]
     int16_t *m_SYM = nullptr, *m_COMP = nullptr;
     uint8_t *m_COND = nullptr, *m_IDX = nullptr, *m_CIDX = nullptr;
-    size_t m_idx_region = 0;          // bytes per decode round trip in m_CIDX / m_h_idx: 16 (count) + its symbols
     int8_t *m_DECODED = nullptr, *m_YQ = nullptr;
     int32_t *m_CNT = nullptr, *m_TOTALS = nullptr;
     Pinned<int32_t> m_h_totals;

@@ -117,8 +117,7 @@ void DmcLdCodec::prepare(int height, int width)
     m_COMP = static_cast<int16_t*>(m_bmem.alloc(n * 2));
     m_COND = static_cast<uint8_t*>(m_bmem.alloc(n / 8 + 8));
     m_IDX = static_cast<uint8_t*>(m_bmem.alloc(n));
-    m_idx_region = (16 + n + 15) / 16 * 16;       // [count, int32 | 12 B pad | compacted indexes]
-    m_CIDX = static_cast<uint8_t*>(m_bmem.alloc(m_idx_region));
+    m_CIDX = static_cast<uint8_t*>(m_bmem.alloc(n));
     m_DECODED = static_cast<int8_t*>(m_bmem.alloc(n));
     m_YQ = static_cast<int8_t*>(m_bmem.alloc(n));
     m_CNT = static_cast<int32_t*>(m_bmem.alloc(sizeof(int32_t) * symbol_blocks(static_cast<int>(n))));
@@ -126,7 +125,7 @@ void DmcLdCodec::prepare(int height, int width)
     m_h_totals.reserve(16);
     m_h_sym.reserve(n);
     m_h_z.reserve(P64 * kChZ + 64);
-    m_h_idx.reserve(m_idx_region);
+    m_h_idx.reserve(n);
     m_h_dec.reserve(n);
 }
 
@@ -383,25 +382,20 @@ void DmcLdCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heig
         d.index = m_IDX; d.cond = m_COND; d.block_count = m_CNT;
         d.H = g.H16; d.W = g.W16; d.C = kChY; d.skip_thres = m_skip_thres;
         mask_dec_index(d, st);
-        compact(m_IDX, 1, m_COND, m_CNT, ny, m_CIDX + 16, reinterpret_cast<int32_t*>(m_CIDX), 0, st);
+        compact(m_IDX, 1, m_COND, m_CNT, ny, m_CIDX, m_TOTALS, 0, st);
     });
-    // [count | indexes]: the count and the first kFirst index bytes in ONE copy, no synchronisation in front of the
-    // context network
-    constexpr size_t kFirst = 192 * 1024;
-    const size_t first = std::min(m_idx_region, 16 + kFirst);
-    hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX, first, hipMemcpyDeviceToHost, st), "D2H count + indexes");
-    hip_check(hipEventRecord(m_ev_idx, st), "hipEventRecord");
+    hip_check(hipMemcpyAsync(m_h_totals.get(), m_TOTALS, sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H totals");
+    hip_check(hipStreamSynchronize(st), "sync");
+    const int n = m_h_totals[0];
+    if (n > 0) {
+        hip_check(hipMemcpyAsync(m_h_idx.get(), m_CIDX, n, hipMemcpyDeviceToHost, st), "D2H indexes");
+        hip_check(hipEventRecord(m_ev_idx, st), "hipEventRecord");
+    }
     // the context network runs while the host decodes y (dmc_ld_proxy.cpp:556-560)
     run_stage(kDec2, st, [&] { run_fe(st); });
-    hip_check(hipEventSynchronize(m_ev_idx), "hipEventSynchronize");
-    const int n = *reinterpret_cast<const int32_t*>(m_h_idx.get());
-    if (n < 0 || n > ny) throw std::runtime_error("DMC-LD decompress: bad symbol count");
-    if (16 + static_cast<size_t>(n) > first) {
-        hip_check(hipMemcpyAsync(m_h_idx.get() + first, m_CIDX + first, 16 + n - first, hipMemcpyDeviceToHost, st), "D2H indexes");
-        hip_check(hipStreamSynchronize(st), "sync");
-    }
     if (n > 0) {
-        m_dec.decode_y(m_h_idx.get() + 16, n, m_h_dec.get());
+        hip_check(hipEventSynchronize(m_ev_idx), "hipEventSynchronize");
+        m_dec.decode_y(m_h_idx.get(), n, m_h_dec.get());
         hip_check(hipMemcpyAsync(m_DECODED, m_h_dec.get(), n, hipMemcpyHostToDevice, st), "H2D symbols");
     }
     bind_stage_arg(kDec3, x_hat);
