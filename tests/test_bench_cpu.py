@@ -51,12 +51,12 @@ class _FakeWork:
     def compress(self, i, qp):
         assert qp in bench.QPS
         self.calls.append(("c", i))
-        time.sleep(0.001)
+        time.sleep(0.004)
         return {"bit_stream": b"x" * 1000, "ec_parallel": 1}
 
     def decompress(self, i, qp, enc):
         self.calls.append(("d", i))
-        time.sleep(0.002)
+        time.sleep(0.008)
 
     def set_use_graphs(self, on):
         pass
@@ -115,9 +115,10 @@ def test_one_json_line_with_the_contract_fields(fake_gpu, monkeypatch, capsys):
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
     assert d["value"] == pytest.approx(7 / (d["ms_per_step"] * 7 / 1e3), rel=1e-6)
     assert d["bytes_per_picture"] == 1000
-    # compress takes 1 ms and decompress 2 ms in the stand-in: the two rates are measured separately
+    # compress takes 4 ms and decompress 8 ms in the stand-in: the two rates are measured separately (wide bounds:
+    # sleep() overshoots on a busy host)
     assert d["encode_fps"] > d["decode_fps"] > 0
-    assert 1.5 < d["encode_fps"] / d["decode_fps"] < 2.6
+    assert 1.3 < d["encode_fps"] / d["decode_fps"] < 2.8
     assert set(d["other_workloads"]) == {"ld", "hts", "htl"}
     for kind, o in d["other_workloads"].items():
         assert set(o) >= {"value", "encode_fps", "decode_fps", "ms_per_step"} and o["value"] > 0
