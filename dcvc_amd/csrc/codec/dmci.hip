@@ -329,7 +329,7 @@ void DmciCodec::decompress(const uint8_t* bits, size_t nbytes, int qp, int heigh
     // the first copy of a step takes the count and up to kFirst index bytes (a 1080p step has 50-130 k of its 522 k
     // possible symbols): one copy + one synchronisation per step instead of two of each (the second pair cost
     // ~25 us of GPU idle time per step in the kernel trace)
-    constexpr size_t kFirst = 192 * 1024;
+    static const size_t kFirst = [] { const char* e = getenv("DCVC_IDX_FIRST_KB"); return static_cast<size_t>(e ? atoi(e) : 192) * 1024; }();
     for (int k = 0; k < 4; ++k) {
         // one GPU -> CPU -> GPU round trip per autoregressive step (dmci_proxy.cpp:857-871)
         auto t_w = clk::now();
