@@ -69,31 +69,49 @@ WeightFile load_weights(const std::string& path)
     if (!f) die("cannot open " + path);
     const std::streamsize size = f.tellg();
     f.seekg(0);
+    if (size < 20) die(path + " is not a .dcvw file");
     w.blob.resize(static_cast<size_t>(size));
-    f.read(w.blob.data(), size);
+    if (!f.read(w.blob.data(), size)) die("cannot read " + path);
     const char* p = w.blob.data();
     const char* end = p + size;
-    if (size < 20 || std::memcmp(p, "DCVW1\0\0\0", 8) != 0) die(path + " is not a .dcvw file");
+    if (std::memcmp(p, "DCVW1\0\0\0", 8) != 0) die(path + " is not a .dcvw file");
     p += 8;
     uint32_t kind, count;
     std::memcpy(&kind, p, 4); std::memcpy(&w.skip_thres, p + 4, 4); std::memcpy(&count, p + 8, 4);
     p += 12;
     w.kind = static_cast<int>(kind);
+    // every field is checked against the end of the file before it is read: the file comes from the user
+    auto need = [&](uint64_t bytes, const char* what) {
+        if (static_cast<uint64_t>(end - p) < bytes) die(path + ": truncated (" + what + ")");
+    };
     for (uint32_t i = 0; i < count; ++i) {
         const char* rec = p;
-        if (end - p < 4) die(path + ": truncated");
+        need(2, "name length");
         uint16_t nl;
         std::memcpy(&nl, p, 2); p += 2;
+        need(static_cast<uint64_t>(nl) + 2, "name");
         w.names.emplace_back(p, nl); p += nl;
         const int dtype = static_cast<uint8_t>(p[0]), nd = static_cast<uint8_t>(p[1]); p += 2;
+        if (dtype > 2 || nd > 8) die(path + ": bad record " + w.names.back());
         w.dtypes.push_back(dtype); w.ndims.push_back(nd);
-        for (int d = 0; d < nd; ++d) { int64_t v; std::memcpy(&v, p, 8); p += 8; w.dims.push_back(v); }
+        need(8ull * nd + 8, "dimensions");
+        uint64_t elems = 1;
+        for (int d = 0; d < nd; ++d) {
+            int64_t v;
+            std::memcpy(&v, p, 8); p += 8;
+            if (v < 0 || (v > 0 && elems > (1ull << 40) / static_cast<uint64_t>(v))) die(path + ": bad shape of " + w.names.back());
+            elems *= static_cast<uint64_t>(v);
+            w.dims.push_back(v);
+        }
         uint64_t nbytes;
         std::memcpy(&nbytes, p, 8); p += 8;
-        if (static_cast<uint64_t>(end - p) < nbytes) die(path + ": truncated tensor " + w.names.back());
+        if (nbytes != elems * (dtype == 0 ? 2u : 4u)) die(path + ": size of " + w.names.back() + " does not match its shape");
+        need(nbytes, "tensor data");
         w.data.push_back(p);
         p += nbytes;
-        p += (8 - ((p - rec) & 7)) & 7;
+        const size_t pad = (8 - ((p - rec) & 7)) & 7;
+        if (static_cast<size_t>(end - p) < pad && i + 1 < count) die(path + ": truncated (padding)");
+        p += std::min<size_t>(pad, static_cast<size_t>(end - p));
     }
     for (const std::string& n : w.names) w.name_ptrs.push_back(n.c_str());
     return w;
@@ -115,6 +133,7 @@ Codecs make_codecs(const std::string& intra_path, const std::string& inter_path)
         const WeightFile w = load_weights(intra_path);
         if (w.kind != 0) die(intra_path + " does not hold an intra model");
         c.intra = dcvc_dmci_create();
+        if (c.intra == nullptr) die(std::string("cannot create the intra codec: ") + dcvc_last_error());
         abi_ok(dcvc_dmci_set_param(c.intra, static_cast<int>(w.names.size()), w.name_ptrs.data(), w.data.data(),
                                    w.dtypes.data(), w.ndims.data(), w.dims.data(), w.skip_thres), "intra set_param");
     }
@@ -123,10 +142,12 @@ Codecs make_codecs(const std::string& intra_path, const std::string& inter_path)
         const int n = static_cast<int>(w.names.size());
         if (w.kind == 1) {
             c.ld = dcvc_dmcld_create();
+            if (c.ld == nullptr) die(std::string("cannot create the inter codec: ") + dcvc_last_error());
             abi_ok(dcvc_dmcld_set_param(c.ld, n, w.name_ptrs.data(), w.data.data(), w.dtypes.data(), w.ndims.data(),
                                         w.dims.data(), w.skip_thres), "inter set_param");
         } else if (w.kind == 2 || w.kind == 3) {
             c.ht = dcvc_dmcht_create(w.kind == 2);
+            if (c.ht == nullptr) die(std::string("cannot create the inter codec: ") + dcvc_last_error());
             c.frames_per_p = 8;
             abi_ok(dcvc_dmcht_set_param(c.ht, n, w.name_ptrs.data(), w.data.data(), w.dtypes.data(), w.ndims.data(),
                                         w.dims.data(), w.skip_thres), "inter set_param");
