@@ -138,3 +138,80 @@ def test_inter_workload_line(fake_gpu, monkeypatch, capsys):
     assert d["config"]["pictures_per_step"] == 8 and "HT-S" in d["metric"]
     assert d["value"] == pytest.approx(8 * 4 / (d["ms_per_step"] * 4 / 1e3), rel=1e-6)
     assert "cpu_baseline" not in d                        # the CPU baseline belongs to the headline workload
+
+
+class _FakeDist:
+    """stands in for torch.distributed inside bench.main(): one process plays one rank of a 2-GPU launch"""
+    ReduceOp = type("ReduceOp", (), {"MAX": "max"})
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.barriers, self.reduced = rank, world, 0, 0
+
+    def init_process_group(self, backend=None, device_id=None, **k):
+        assert backend == "nccl"
+
+    def barrier(self):
+        self.barriers += 1
+
+    def all_reduce(self, t, op=None):
+        assert op == "max"
+        self.reduced += 1
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def destroy_process_group(self):
+        pass
+
+
+@pytest.mark.parametrize("rank", [0, 1])
+def test_one_rank_of_a_two_gpu_launch(fake_gpu, monkeypatch, capsys, rank):
+    """The driver launches `bench.py --gpus 2` under torch.distributed.run: every rank codes its own share of the
+    2 K steps (sharding.shard_range), rank 0 alone prints the line, with the aggregate over both ranks."""
+    fake = _FakeDist(rank, 2)
+    monkeypatch.setitem(sys.modules, "torch.distributed", fake)
+    monkeypatch.setattr(torch, "distributed", fake, raising=False)
+    monkeypatch.setattr(torch, "tensor", lambda data, dtype=None, device=None: torch.as_tensor(data, dtype=dtype))
+    monkeypatch.setenv("RANK", str(rank))
+    monkeypatch.setenv("LOCAL_RANK", str(rank))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-roofline"])
+    bench.main()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    w = _FakeWork.made[0]
+    timed = [c[1] for c in w.calls if c[0] == "c"][1:5]
+    assert timed == [1 + 4 * rank + i for i in range(4)]          # warm-up step 0, then this rank's share of the 8 steps
+    assert fake.barriers >= 3 and fake.reduced == 1
+    if rank == 1:
+        assert lines == []
+        return
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4
+    assert d["value"] == pytest.approx(2 * 4 / (d["ms_per_step"] * 4 / 1e3), rel=1e-6)
+    assert "other_workloads" not in d and "cpu_baseline" not in d          # single-GPU extras only at N = 1
+
+
+def test_fan_out_line(fake_gpu, monkeypatch, capsys):
+    """`--fanout` (one hierarchical stream over all ranks): strong scaling, every rank takes part in the per-call
+    timing loop, the value counts the stream's pictures once."""
+    fake = _FakeDist(0, 2)
+    monkeypatch.setitem(sys.modules, "torch.distributed", fake)
+    monkeypatch.setattr(torch, "distributed", fake, raising=False)
+    monkeypatch.setattr(torch, "tensor", lambda data, dtype=None, device=None: torch.as_tensor(data, dtype=dtype))
+    monkeypatch.setattr(bench, "FanoutWorkload", lambda kind, device, pics, net, pb, pr, dist: _FakeInter(kind))
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--workload", "hts", "--fanout", "--steps", "3", "--warmup", "1"])
+    bench.main()
+    d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.strip()][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["sharding"] == "recon-head fan-out"
+    assert d["value"] == pytest.approx(8 * 3 / (d["ms_per_step"] * 3 / 1e3), rel=1e-6)
+    assert "roofline" not in d
+    with pytest.raises(SystemExit):
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "ld", "--fanout"])
+        bench.main()
