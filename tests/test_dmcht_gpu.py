@@ -253,6 +253,7 @@ def _fanout_rank(rank, world, port, structure, out_path):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL broadcast of feature_p over xGMI)")
 def test_recon_head_fan_out_over_rccl(tmp_path):
     import pickle
