@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """bench.py - DCVC-UF 1080p YUV420 encode + decode throughput on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload intra|ld|hts|htl]
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--workload intra|ld|hts|htl] [--resolution 3840x2160]
+  N > 1: either under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+  LOCAL_RANK / WORLD_SIZE in the environment), or plainly `python bench.py --gpus N ...`: without WORLD_SIZE the
+  process re-launches itself under torch.distributed.run, one rank per GPU over RCCL (launch_ranks()).
 
 Headline workload (BASELINE.json configs[1]): DCVC-UF-Intra (DMCI, 42.2 M parameters, seeded synthetic
 weights of the reference architecture), 1920x1080 YUV420 synthetic pictures, q_index cycling over
@@ -20,10 +22,15 @@ The JSON line (rank 0) carries, besides the driver contract:
                             around every compress / decompress call, the first 4 calls dropped,
                             pictures per call / mean call time. A separate pass after the timed region.
   other_workloads           the same three numbers for the other three models (short runs; N = 1 only)
-  roofline                  the contraction kernels (dcb_core + conv_gemm: > 99 % of the FLOPs): algorithmic
-                            FLOPs / HIP-event time of their launches, stamped live on the codec's stream
-                            by hipExtLaunchKernelGGL in an extra eager pass; per-kernel split; HBM traffic
-                            of the dominant kernel from the committed PMC pass named in `traffic_source`
+  roofline                  the DOMINANT contraction kernel (most time per step): its algorithmic FLOPs / the
+                            HIP-event time of its launches, stamped live on the codec's stream by
+                            hipExtLaunchKernelGGL in an extra eager pass; `all_contractions` = every contraction
+                            launch together (> 99 % of the FLOPs), `kernels` = the per-kernel split; HBM
+                            traffic from the committed PMC pass named in `traffic_source` (null when the
+                            kernel sources changed since that pass)
+  sustained                 the same loop run for >= --min-seconds after the K timed steps (the K-step region
+                            of a short driver run is a fraction of a second)
+  uhd                       short 3840x2160 runs of all four workloads (BASELINE configs[4]'s resolution)
   cpu_baseline              the reference's CPU-runnable path (fp32 graph forward_one_frame, restated in
                             oracle/torch_graph.py) on this host: all cores = `value`, one thread beside it
                             (the reference's set_torch_env pins 1, common.py:270), and the bit-exact
@@ -44,7 +51,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HEIGHT, WIDTH = 1080, 1920
+HEIGHT, WIDTH = 1080, 1920          # default resolution (BASELINE configs[1]); --resolution overrides
 QPS = (0, 16, 32, 48, 63)
 SKIP_THRES = 0.15
 MFMA_PEAK_TFLOPS = 2500.0        # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
@@ -69,7 +76,37 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the short runs of the other three workloads")
-    return p.parse_args()
+    p.add_argument("--resolution", default="%dx%d" % (WIDTH, HEIGHT), help="WxH of the synthetic pictures (3840x2160 = configs[4])")
+    p.add_argument("--no-uhd", action="store_true", help="skip the short 3840x2160 runs of the default line")
+    p.add_argument("--min-seconds", type=float, default=2.0,
+                   help="length of the `sustained` region behind the K timed steps (0 = none)")
+    a = p.parse_args()
+    try:
+        w, h = (int(v) for v in a.resolution.lower().split("x"))
+        assert w > 0 and h > 0 and w % 2 == 0 and h % 2 == 0
+    except (ValueError, AssertionError):
+        raise SystemExit("--resolution wants WxH with even W and H, e.g. 1920x1080")
+    a.width, a.height = w, h
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    return a
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: re-run this very command line under
+    torch.distributed.run, one rank per GPU (the reference's scaling mode is one worker process per GPU,
+    test_video.py:407-420,496-500). Rank 0's JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def _to_gpu(net, device):
@@ -87,11 +124,11 @@ def build_model(device):
     return net, _to_gpu(net, device)
 
 
-def make_pictures(n, rank, device):
+def make_pictures(n, rank, device, height=HEIGHT, width=WIDTH):
     from dcvc_amd import synthetic
     pics = []
     for i in range(n):
-        y, uv = synthetic.synthetic_frame_yuv420(HEIGHT, WIDTH, index=i, seed=rank)
+        y, uv = synthetic.synthetic_frame_yuv420(height, width, index=i, seed=rank)
         x = synthetic.yuv420_to_x(y, uv).half().to(device)
         pics.append(x.contiguous(memory_format=torch.channels_last))
     return pics
@@ -107,7 +144,8 @@ class IntraWorkload:
     def __init__(self, gpu_net, pics, pad_b, pad_r, dec_net=None):
         self.net, self.pics, self.pad_b, self.pad_r = gpu_net, pics, pad_b, pad_r
         self.dec = dec_net if dec_net is not None else gpu_net
-        self.sps = {"height": HEIGHT, "width": WIDTH}
+        self.height, self.width = int(pics[0].shape[2]), int(pics[0].shape[3])
+        self.sps = {"height": self.height, "width": self.width}
 
     def prepare(self, i):
         pass
@@ -128,13 +166,16 @@ class IntraWorkload:
 class InterWorkload:
     """configs[2]: P pictures with the inter models, separate encoder / decoder objects (the decoder
     sees only the bytes). Every `gop` steps both sides are re-seeded from an intra reconstruction
-    (add_ref_feature_from_frame; the I picture itself is coded outside the timed calls), LD resets its
-    feature memory every 32 pictures like the reference default (test_video.py:148,232)."""
+    (add_ref_feature_from_frame; the I picture itself is coded outside the timed calls); the feature memory is
+    reset at the reference's cadence (test_video.py:148,232-235: reset_interval 32, a call resets when
+    (frame_idx + g_frame_delay) % reset_interval == 1 - every 32nd picture for LD, every 4th chunk for HT)."""
+    RESET_INTERVAL = 32
 
     def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r):
         from dcvc_amd import arch, models, synthetic
         self.kind, self.pad_b, self.pad_r = kind, pad_b, pad_r
-        self.sps = {"height": HEIGHT, "width": WIDTH}
+        self.height, self.width = int(pics[0].shape[2]), int(pics[0].shape[3])
+        self.sps = {"height": self.height, "width": self.width}
         if kind == "ld":
             net = models.DMC()
             net.load_state_dict(synthetic.synthetic_state_dict(arch.dmc_ld_spec(), 0))
@@ -155,8 +196,9 @@ class InterWorkload:
         self.default_graphs = kind != "ld"
 
     def _reset(self, i):
-        # picture index inside the GOP (0 = the I picture); (frame_idx + g_frame_delay) % reset_interval == 1
-        return 1 if (self.frames == 1 and (i % self.gop + 1) % 32 == 0) else 0
+        # step i codes the pictures frame_idx .. frame_idx + frames - 1 of its GOP, frame 0 being the I picture
+        frame_idx = 1 + self.frames * (i % self.gop)
+        return 1 if (frame_idx + self.frames) % self.RESET_INTERVAL == 1 else 0
 
     def prepare(self, i):
         if i % self.gop == 0:
@@ -176,9 +218,9 @@ class InterWorkload:
 
 class FanoutWorkload(InterWorkload):
     """ONE hierarchical stream decoded over all ranks. Rank 0 owns the stream (encoder and the
-    decoder's entropy / prior / decoder stages, temporal state); after its decode it broadcasts feature_p over
-    RCCL and every rank reconstructs its share of the 8 pictures (dcvc_amd/sharding.py decompress_fanout).
-    Strong scaling: the work of a step does not grow with the number of GPUs."""
+    decoder's entropy / prior / decoder stages, temporal state); it broadcasts feature_p over RCCL while its own
+    reconstruction heads run, and every rank reconstructs its share of the 8 pictures
+    (dcvc_amd/sharding.py decompress_fanout). Strong scaling: the work of a step does not grow with the number of GPUs."""
 
     def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r, dist):
         super().__init__(kind, device, pics, gpu_intra, pad_b, pad_r)
@@ -198,7 +240,7 @@ class FanoutWorkload(InterWorkload):
     def decompress(self, i, qp, enc):
         from dcvc_amd import sharding
         return sharding.decompress_fanout(self.dec._ensure_proxy(), np.frombuffer(enc["bit_stream"], dtype=np.uint8), qp,
-                                          HEIGHT, WIDTH, enc["ec_parallel"], bool(self._reset(i)), self.dist)
+                                          self.height, self.width, enc["ec_parallel"], bool(self._reset(i)), self.dist)
 
     def set_use_graphs(self, on):
         for g in (self.enc, self.dec):
@@ -241,7 +283,7 @@ def call_times(work, first, n):
     return float(np.mean(enc_t[keep])), float(np.mean(dec_t[keep]))
 
 
-def fps_block(work, first, steps, warmup):
+def fps_block(work, first, steps, warmup, with_roofline=False):
     """throughput (pipelined loop) + the reference-style encode / decode rates of one workload"""
     run_steps(work, first, warmup)
     torch.cuda.synchronize()
@@ -250,9 +292,13 @@ def fps_block(work, first, steps, warmup):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     te, td = call_times(work, first + warmup + steps, min(steps, 24) + DROP_CALLS)
-    return {"value": steps * work.frames / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
-            "encode_fps": work.frames / te, "decode_fps": work.frames / td,
-            "bpp": 8.0 * nbytes / steps / work.frames / (HEIGHT * WIDTH)}
+    out = {"value": steps * work.frames / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "encode_fps": work.frames / te, "decode_fps": work.frames / td,
+           "bpp": 8.0 * nbytes / steps / work.frames / (work.height * work.width)}
+    if with_roofline:
+        r = roofline(work, n=2)
+        out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "all_contractions")}
+    return out
 
 
 def cpu_baseline(cpu_net):
@@ -294,8 +340,40 @@ def cpu_baseline(cpu_net):
     }
 
 
-def roofline(work):
-    """contraction launches of 5 steps bracketed by HIP events (eager pass on the codec's stream)"""
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
+KERNEL_SOURCES = ("dcb_core.hip", "conv_gemm.hip", "dcb_tail.hip", "ffn_fused.hip", "dwconv.hip", "arith.h")
+
+
+def kernel_source_digest():
+    """sha256 over the contraction kernels' sources: ties a committed PMC pass to the code it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "dcvc_amd", "csrc", "kernels", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/hbm_traffic.py), or
+    (None, reason) when there is no pass for the kernel sources as they are now"""
+    try:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+            t = json.load(f)
+        if t.get("kernel_source_digest") != kernel_source_digest():
+            return None, "%s was collected for other kernel sources (digest %s, now %s): not reported" % (
+                TRAFFIC_FILE, t.get("kernel_source_digest"), kernel_source_digest())
+        return t["kernels"][kernel]["hbm_bytes_per_launch"], "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of " \
+            "`bench.py --steps 5`, kernel sources %s)" % (TRAFFIC_FILE, t["kernel_source_digest"])
+    except (OSError, KeyError, ValueError) as e:
+        return None, "no PMC pass on file (%s)" % type(e).__name__
+
+
+KERNEL_NAMES = {0: "conv_gemm_kernel", 1: "dcb_core_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "prior_chain_kernel"}
+
+
+def roofline(work, n=len(QPS)):
+    """contraction launches of n steps bracketed by HIP events (eager pass on the codec's stream)"""
     from dcvc_amd import _lib
     en = _lib.fn("dcvc_gemm_profile_enable", ctypes.c_int, [ctypes.c_int])
     rs = _lib.fn("dcvc_gemm_profile_reset", ctypes.c_int, [])
@@ -305,17 +383,18 @@ def roofline(work):
     torch.cuda.synchronize()
     _lib.check(en(1))
     _lib.check(rs())
-    n = len(QPS)
     run_steps(work, 2, n)
     torch.cuda.synchronize()
     rec = np.dtype([("M", np.int32), ("N", np.int32), ("K", np.int32), ("variant", np.int32), ("ms", np.float32)])
-    buf = np.zeros(65536, dtype=rec)
+    buf = np.zeros(131072, dtype=rec)
     used = int(ln(buf.ctypes.data, len(buf)))
     buf = buf[:used]
     _lib.check(en(0))
     work.set_use_graphs(work.default_graphs)
     flops = 2.0 * buf["M"].astype(np.float64) * buf["N"] * buf["K"]
-    core = buf["variant"] < 0                            # bit 31: dcb_core launches
+    # variant bits 28..31: the kernel family of the launch (ops.h GemmLaunchInfo); 8 = dcb_core (the sign bit)
+    fam = (buf["variant"].astype(np.int64) >> 28) & 0xF
+    family = np.where(fam >= 8, 1, fam)
     if os.environ.get("DCVC_BENCH_SHAPES"):
         agg = {}
         for r, f in zip(buf, flops):
@@ -338,46 +417,48 @@ def roofline(work):
         return {"kernel": name, "launches_per_step": cnt / n, "avg_launch_us": 1e3 * ms / cnt, "ms_per_step": ms / n,
                 "gflop_per_step": fl / n / 1e9, "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                 "algorithmic_bytes_per_launch": alg_bytes}
-    # algorithmic bytes per launch (every operand once). dcb_core at 1080p: the depthwise output and the
-    # block input in, the block output and the next block's dc.0 output out ([32640][384] fp16 each) + 2.06 MB of weights
-    P8 = 32640 if (HEIGHT, WIDTH) == (1080, 1920) else None
-    core_bytes = None if P8 is None else 4 * P8 * 384 * 2 + 7 * 384 * 384 * 2
-    kernels = [k for k in (part(core, "dcb_core_kernel", core_bytes), part(~core, "conv_gemm_kernel", None)) if k]
+    # algorithmic bytes per launch (every operand once). dcb_core: the depthwise output and the block input
+    # in, the block output and the next block's dc.0 output out ([P8][384] fp16 each) + 2.06 MB of weights
+    P8 = ((work.height + 15) // 16 * 2) * ((work.width + 15) // 16 * 2)
+    core_bytes = 4 * P8 * 384 * 2 + 7 * 384 * 384 * 2
+    kernels = [k for k in (part(family == f, name, core_bytes if f == 1 else None) for f, name in KERNEL_NAMES.items()) if k]
     total_ms, total_fl = float(buf["ms"].sum()), float(flops.sum())
     dom = max(kernels, key=lambda k: k["ms_per_step"])
-    traffic, source = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
-            t = json.load(f)
-        traffic = t["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
-        source = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command at commit %s)" % t.get("commit", "?")
-    except (OSError, KeyError, ValueError):
-        pass
-    achieved = total_fl / (total_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": dom["kernel"], "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
+    traffic, source = pmc_traffic(dom["kernel"])
+    return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["frac"], "traffic": traffic, "traffic_source": source,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-            "note": "achieved / frac = all contraction launches of the step together (dcb_core + conv_gemm: > 99 % of the FLOPs); "
-                    "`kernel` is the one with the most time, per-kernel figures under `kernels`",
-            "launches_per_step": used / n, "gflop_per_step": total_fl / n / 1e9, "contraction_ms_per_step": total_ms / n,
+            "note": "achieved / frac / traffic = the dominant kernel's own launches (`kernel`: the contraction kernel with the most "
+                    "time per step); all_contractions = every contraction launch of the step together (> 99 % of the FLOPs)",
+            "all_contractions": {"achieved": total_fl / (total_ms * 1e-3) / 1e12, "frac": total_fl / (total_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                 "launches_per_step": used / n, "gflop_per_step": total_fl / n / 1e9, "ms_per_step": total_ms / n},
             "kernels": kernels}
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # as the reference harness (test_video.py:423-425): the process works on a non-default stream
     torch.cuda.set_stream(torch.cuda.Stream(device))
-    dist = None
+    dist, comm_device = None, device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("DCVC_BENCH_BACKEND", "nccl")       # "gloo": the CPU test of the launch path
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
+            comm_device = torch.device("cpu")
     import __graft_entry__
     if rank == 0:
         with contextlib.redirect_stdout(sys.stderr):     # stdout carries the ONE JSON line and nothing else
@@ -385,11 +466,12 @@ def main():
     if dist is not None:
         dist.barrier()
 
+    height, width = args.height, args.width
     cpu_net, gpu_net = build_model(device)
-    pics = make_pictures(args.frames, rank, device)
-    pad_r, pad_b = gpu_net.get_padding_size(HEIGHT, WIDTH, 16)
 
-    def make_work(kind):
+    def make_work(kind, h, w, frames=args.frames):
+        pics = make_pictures(frames, rank, device, h, w)
+        pad_r, pad_b = gpu_net.get_padding_size(h, w, 16)
         if kind == "intra":
             return IntraWorkload(gpu_net, pics, pad_b, pad_r, _to_gpu(cpu_net, device) if args.two_codecs else None)
         return InterWorkload(kind, device, pics, gpu_net, pad_b, pad_r)
@@ -397,7 +479,12 @@ def main():
     fanout = args.fanout and world > 1
     if args.fanout and args.workload not in ("hts", "htl"):
         raise SystemExit("--fanout needs --workload hts or htl (the models with 8 reconstruction heads per call)")
-    work = FanoutWorkload(args.workload, device, pics, gpu_net, pad_b, pad_r, dist) if fanout else make_work(args.workload)
+    if fanout:
+        pics = make_pictures(args.frames, rank, device, height, width)
+        pad_r, pad_b = gpu_net.get_padding_size(height, width, 16)
+        work = FanoutWorkload(args.workload, device, pics, gpu_net, pad_b, pad_r, dist)
+    else:
+        work = make_work(args.workload, height, width)
     # independent streams: rank r codes the steps shard_range() gives it out of world * steps (weak scaling,
     # no data-path collective); fan-out: every rank takes part in every step
     from dcvc_amd import sharding
@@ -409,16 +496,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     run_steps(work, 0, args.warmup)
     sync()
     t0 = time.perf_counter()
     nbytes = run_steps(work, args.warmup + mine.start, args.steps)
     sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    # the same loop for >= --min-seconds: the K-step region of a short driver run lasts a fraction of a second
+    sustained = None
+    if args.min_seconds > 0:
+        more = max(args.steps, int(np.ceil(args.min_seconds * args.steps / max(elapsed, 1e-6))))
+        more = min(more, 100 * args.steps)
+        sync()
+        t0 = time.perf_counter()
+        run_steps(work, args.warmup + mine.start + args.steps, more)
+        sync()
+        t_more = max_over_ranks(time.perf_counter() - t0)
+        sustained = {"steps": more, "seconds": t_more, "value": (1 if fanout else world) * more * work.frames / t_more,
+                     "unit": "frames/s"}
 
     if fanout:       # every rank takes part in the per-call timing loop (the broadcast is a collective)
         te, td = call_times(work, args.warmup + args.steps, min(args.steps, 32) + DROP_CALLS)
@@ -426,39 +529,53 @@ def main():
         if not fanout:
             te, td = call_times(work, args.warmup + args.steps, min(args.steps, 32) + DROP_CALLS)
         fps = (1 if fanout else world) * args.steps * work.frames / elapsed
+        res = "%dx%d" % (width, height)
         out = {
-            "metric": "1080p YUV420 %s encode+decode pictures per second (%s, real rANS bit streams, q_index in {0,16,32,48,63})"
-                      % ("intra" if args.workload == "intra" else "inter", NAMES[args.workload]),
+            "metric": "%s YUV420 %s encode+decode pictures per second (%s, real rANS bit streams, q_index in {0,16,32,48,63})"
+                      % ("1080p" if (height, width) == (1080, 1920) else res, "intra" if args.workload == "intra" else "inter",
+                         NAMES[args.workload]),
             "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if fanout else "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the reference architecture)",
-            "config": {"workload": ("%s 1080p YUV420, ONE stream over all ranks (rank 0 codes, feature_p broadcast, reconstruction "
-                                    "heads fanned out), " if fanout else "%s 1080p YUV420 on 1xMI355X per rank, ") % NAMES[args.workload]
+            "config": {"workload": ("%s " + res + " YUV420, ONE stream over all ranks (rank 0 codes, feature_p broadcast, reconstruction "
+                                    "heads fanned out), " if fanout else "%s " + res + " YUV420 on 1xMI355X per rank, ") % NAMES[args.workload]
                                    + "q_index cycling {0,16,32,48,63}, skip_thres 0.15, one step = compress + decompress of %d "
                                      "picture(s)" % work.frames,
                        "sharding": "recon-head fan-out" if fanout else "independent streams (sharding.shard_range)",
                        "codec_objects": "one" if (args.workload == "intra" and not args.two_codecs) else "separate encoder / decoder",
-                       "pictures_per_step": work.frames, "resolution": "%dx%d" % (WIDTH, HEIGHT)},
+                       "pictures_per_step": work.frames, "resolution": res},
             "encode_fps": work.frames / te, "decode_fps": work.frames / td,
             "avg_frame_encoding_time_ms": 1e3 * te / work.frames, "avg_frame_decoding_time_ms": 1e3 * td / work.frames,
             "fps_method": "value: K pipelined steps between device synchronisations; encode_fps / decode_fps: the reference's loop "
                           "(events around each call on a synchronised device, first %d calls dropped, rank 0)" % DROP_CALLS,
             "bytes_per_picture": nbytes / args.steps / work.frames,
-            "bpp": 8.0 * nbytes / args.steps / work.frames / (HEIGHT * WIDTH),
+            "bpp": 8.0 * nbytes / args.steps / work.frames / (height * width),
         }
+        if sustained is not None:
+            out["sustained"] = sustained
         if not args.no_roofline and not fanout:
             out["roofline"] = roofline(work)
         if world == 1 and not args.no_extras:
+            del work
+            torch.cuda.empty_cache()
             others = {}
             for kind in NAMES:
                 if kind == args.workload:
                     continue
-                w = make_work(kind)
-                others[kind] = fps_block(w, 0, 24 if kind in ("hts", "htl") else 48, 6)
+                w = make_work(kind, height, width)
+                others[kind] = fps_block(w, 0, 24 if kind in ("hts", "htl") else 48, 6, with_roofline=not args.no_roofline)
                 del w
                 torch.cuda.empty_cache()
             out["other_workloads"] = others
+            if not args.no_uhd and (height, width) == (HEIGHT, WIDTH):
+                uhd = {"resolution": "3840x2160"}
+                for kind in NAMES:
+                    w = make_work(kind, 2160, 3840, frames=2)
+                    uhd[kind] = fps_block(w, 0, 6 if kind in ("hts", "htl") else 12, 3, with_roofline=not args.no_roofline)
+                    del w
+                    torch.cuda.empty_cache()
+                out["uhd"] = uhd
         if world == 1 and not args.no_cpu_baseline and args.workload == "intra":
             out["cpu_baseline"] = cpu_baseline(cpu_net)
         print(json.dumps(out), flush=True)

@@ -9,7 +9,10 @@
 //
 //   dcvc encode --intra I.dcvw [--inter P.dcvw] -i in.yuv -W 1920 -H 1080 [-n frames] --qp-i 32 [--qp-p 32]
 //               [--intra-period -1] [--reset-interval 32] -o out.bin
-//   dcvc decode --intra I.dcvw [--inter P.dcvw] -i out.bin [-o rec.yuv] [--ref in.yuv --json log.json]
+//   dcvc decode --intra I.dcvw [--inter P.dcvw] -i out.bin [-o rec.yuv] [-n frames] [--ref in.yuv --json log.json]
+//               (the container carries no picture count: the last chunk of an 8-picture model is padded by repeating
+//               the final picture, test_video.py:104-110 - give -n, or --ref whose length then trims the output, as the
+//               reference's maximum_read = min(g_frame_delay, frame_num - decoded) does)
 //
 // Picture-type decisions, reset rule, chunk padding, container, PSNR ((6 Y + U + V) / 8 on the
 // 0..255 planes) and the JSON log (what compare_bd_rate.py / dcvc_amd/bd_rate.py read) follow
@@ -174,6 +177,8 @@ Geometry geometry(int H, int W)
     return g;
 }
 
+constexpr int kMaxPictureSide = 16384;      // sanity cap for sizes read from a stream (8K is 7680 x 4320)
+
 struct DeviceBuffers {
     uint8_t* yuv8 = nullptr;       // staging for one u8 picture (planes)
     void* x = nullptr;             // fp16 [H][W][3 * frames]
@@ -197,6 +202,18 @@ DeviceBuffers make_buffers(const Geometry& g, int frames)
     hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b.h_yuv), g.frame_bytes(), hipHostMallocDefault), "hipHostMalloc");
     hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b.h_p16), g.frame_bytes() * 2, hipHostMallocDefault), "hipHostMalloc");
     return b;
+}
+
+void free_buffers(DeviceBuffers& b)
+{
+    if (b.st) hip_ok(hipStreamSynchronize(b.st), "sync");
+    for (void* d : {static_cast<void*>(b.yuv8), b.x, b.x_hat, b.y16, static_cast<void*>(b.out8)}) {
+        if (d) hip_ok(hipFree(d), "hipFree");
+    }
+    if (b.h_yuv) hip_ok(hipHostFree(b.h_yuv), "hipHostFree");
+    if (b.h_p16) hip_ok(hipHostFree(b.h_p16), "hipHostFree");
+    if (b.st) hip_ok(hipStreamDestroy(b.st), "hipStreamDestroy");
+    b = DeviceBuffers{};
 }
 
 double psnr_plane(const uint8_t* src, const uint16_t* rec16, size_t n)
@@ -351,7 +368,12 @@ int decode(const Args& a)
     size_t pending_sps_bits = 0;
     int decoded = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    while (!rd.at_end() && decoded < limit) {
+    bool source_ended = false;
+    if (c.ht && c.frames_per_p > 1 && !a.has("n") && !ref) {
+        fprintf(stderr, "dcvc: warning: %d-picture chunks and neither -n nor --ref: a short last chunk is written with its "
+                        "padding pictures (the container does not carry the picture count)\n", c.frames_per_p);
+    }
+    while (!rd.at_end() && decoded < limit && !source_ended) {
         int nal = 0, sid = 0;
         const size_t unit_start = rd.position();
         rd.header(nal, sid);
@@ -365,6 +387,12 @@ int decode(const Args& a)
         const dcvc::stream::SpsTable::Sps* s = sps.find(sid);
         if (!s) die("picture refers to an unknown parameter set");
         if (!have_buffers || s->height != g.H || s->width != g.W) {
+            // the size comes straight from the (untrusted) stream: refuse what no model of this family codes
+            // instead of attempting a multi-terabyte allocation
+            if (s->height < 2 || s->width < 2 || s->height > kMaxPictureSide || s->width > kMaxPictureSide) {
+                die("unsupported picture size in the stream: " + std::to_string(s->width) + "x" + std::to_string(s->height));
+            }
+            if (have_buffers) free_buffers(b);     // a stream may switch parameter sets: do not leak the old set
             g = geometry(s->height, s->width);
             b = make_buffers(g, c.frames_per_p);
             src.resize(g.frame_bytes());
@@ -395,16 +423,20 @@ int decode(const Args& a)
             const char* xh = static_cast<const char*>(b.x_hat) + static_cast<size_t>(j) * g.Hp * g.Wp * 3 * 2;
             char* y16 = static_cast<char*>(b.y16);
             abi_ok(dcvc_x_to_yuv420(xh, g.Wp, g.H, g.W, y16, y16 + g.y_bytes() * 2, b.out8, b.out8 + g.y_bytes(), b.st), "x_to_yuv420");
+            // the source first: when it ends inside a chunk, the remaining pictures of the chunk are the encoder's
+            // padding (repeats of the final picture) and must reach neither the log nor rec.yuv
+            if (ref) {
+                if (fread(src.data(), 1, g.frame_bytes(), ref) != g.frame_bytes()) {
+                    if (j > 0) { source_ended = true; break; }
+                    die("reference file is shorter than the stream");
+                }
+            }
             if (rec) {
                 hip_ok(hipMemcpyAsync(b.h_yuv, b.out8, g.frame_bytes(), hipMemcpyDeviceToHost, b.st), "D2H");
                 hip_ok(hipStreamSynchronize(b.st), "sync");
                 if (fwrite(b.h_yuv, 1, g.frame_bytes(), rec) != g.frame_bytes()) die("short write");
             }
             if (ref) {
-                if (fread(src.data(), 1, g.frame_bytes(), ref) != g.frame_bytes()) {
-                    if (j > 0) break;      // padding pictures of a short last chunk have no source
-                    die("reference file is shorter than the stream");
-                }
                 hip_ok(hipMemcpyAsync(b.h_p16, b.y16, g.frame_bytes() * 2, hipMemcpyDeviceToHost, b.st), "D2H");
                 hip_ok(hipStreamSynchronize(b.st), "sync");
                 const size_t ny = g.y_bytes(), nc = ny / 4;
@@ -418,7 +450,7 @@ int decode(const Args& a)
             ++decoded;
         }
     }
-    if (have_buffers) hip_ok(hipStreamSynchronize(b.st), "sync");
+    if (have_buffers) free_buffers(b);
     if (rec) fclose(rec);
     if (ref) fclose(ref);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -379,20 +379,18 @@ conv_gemm_kernel(const ConvGemmParams p)
             if constexpr (CHUNK) {
 #pragma unroll
                 for (int np = 0; np < NT / 2; ++np) {
-                    // z = wsilu(acc) ; s = ((z0 + z1) + z2) + z3 over 4 adjacent channels
+                    // s = chunk sum of wsilu(acc) over 4 adjacent channels (arith.h: one fma chain per group)
                     float s[2][4];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int nt = 2 * np + h;
-                        float z[16];
                         if constexpr (ACT == ACT_WSILU) {
-                            wsilu16<R>(acc[nt][mt], z, tab);
+                            wsilu_chunk16<R>(acc[nt][mt], s[h], tab);
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) z[e] = acc[nt][mt][e];
+                            for (int g = 0; g < 4; ++g)
+                                s[h][g] = ((acc[nt][mt][4 * g] + acc[nt][mt][4 * g + 1]) + acc[nt][mt][4 * g + 2]) + acc[nt][mt][4 * g + 3];
                         }
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) s[h][g] = ((z[4 * g] + z[4 * g + 1]) + z[4 * g + 2]) + z[4 * g + 3];
                     }
                     // lower half-wave collects the 8 outputs of tile 2np, upper half-wave those of 2np+1
                     half8 o;

@@ -127,27 +127,6 @@ __device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, un
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
-template <int N, int RR>
-__device__ __forceinline__ void wsilu_n(float (&v)[N], const float4* tab)
-{
-    float f[N];
-    float4 c[N];
-#pragma unroll
-    for (int e = 0; e < N; ++e) {
-        float t = fmaf(v[e], 16.0f, 128.0f);
-        t = fminf(fmaxf(t, 0.0f), 255.99998f);
-        f[e] = __builtin_amdgcn_fractf(t);
-        c[e] = tab[static_cast<int>(t) * RR];
-    }
-#pragma unroll
-    for (int e = 0; e < N; ++e) {
-        float pp = fmaf(c[e].w, f[e], c[e].z);
-        pp = fmaf(pp, f[e], c[e].y);
-        pp = fmaf(pp, f[e], c[e].x);
-        v[e] = v[e] * pp;
-    }
-}
-
 template <bool TIMELINE>
 __global__ void __launch_bounds__(NTHREADS, 1)
 dcb_core_kernel(const CoreParams p)
@@ -227,8 +206,13 @@ dcb_core_kernel(const CoreParams p)
         q.dst = lds_base + slot * SLAB + wave * 1024;
         return q;
     };
+    // Ablation switches (tools/probes/core_bench.hip builds; the RESULTS ARE WRONG with any of them):
+    //   DCB_EXP_NODMA  no LDS-DMA of weight slabs behind the first four   DCB_EXP_NOBAR  no barrier per slab
+    //   DCB_EXP_NOEPI  the WSiLU pieces of the ffn walk do nothing        DCB_EXP_NOGATHER  polynomial on a constant row
     auto issue_part = [&](const Pending& q, int j) {
+#ifndef DCB_EXP_NODMA
         lds_dma16_s(q.base + j * q.jstride, q.voff, q.dst + j * (NTHREADS * 16));
+#endif
     };
 
     // ---- L2 warm-up. Every workgroup streams the SAME weights at the same time, and L2 starts cold
@@ -297,7 +281,11 @@ dcb_core_kernel(const CoreParams p)
         for (int j = 0; j < LPS; ++j) issue_part(q, j);
     }
 
-    const float4* tab = reinterpret_cast<const float4*>(smem + OFF_TABLE) + (lane & (R - 1));
+    // LDS address of this lane's copy of the WSiLU table; its bits must stay clear of a row offset's (6..13) so
+    // that index mask and base are one v_and_or_b32 (arith.h wsilu_row_lds): the table sits at a multiple of 16 KB
+    static_assert(OFF_TABLE % 16384 == 0 && R == 4, "WSiLU table placement");
+    const unsigned tab = lds_base + OFF_TABLE + (lane & (R - 1)) * 16;
+    if ((lds_base & 16383u) != 0) __builtin_trap();      // dynamic LDS starts at 0 (no static LDS in this kernel)
     float* lbias = reinterpret_cast<float*>(smem + OFF_CONST);
     half_t* lqs = reinterpret_cast<half_t*>(smem + OFF_QSCALE);
     {
@@ -391,7 +379,9 @@ dcb_core_kernel(const CoreParams p)
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef DCB_EXP_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         return plan_slab(g + NS - 1, (slot + NS - 1) % NS);
     };
@@ -712,32 +702,34 @@ dcb_core_kernel(const CoreParams p)
     // the data it needs:  read (in front of the slice's MFMAs) | index + gather (behind them) | polynomial
     // + chunk sum (behind the MFMAs of the NEXT slice).
     float4v pv[2];                 // parked values of the pieces being read / indexed (q & 1)
-    float ev[2][4], ef[2][4];      // values / table fractions of the pieces whose coefficients are in flight (q & 1)
+    float ev[2][4];                // values of the pieces whose coefficients are in flight (q & 1)
     float4 ec[2][4];
     auto piece_read = [&](int q) { pv[q & 1] = parked(q); };
+    // arithmetic policy v3 (arith.h): med3 | add | and-or -> table row; 2 fma + 1 fma (chunk sum) per element
     auto piece_index = [&](int q) {
+#ifndef DCB_EXP_NOEPI
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             ev[q & 1][e] = pv[q & 1][e];
-            float t = fmaf(pv[q & 1][e], 16.0f, 128.0f);
-            t = fminf(fmaxf(t, 0.0f), 255.99998f);
-            ef[q & 1][e] = __builtin_amdgcn_fractf(t);
-            ec[q & 1][e] = tab[static_cast<int>(t) * R];
+#ifdef DCB_EXP_NOGATHER
+            ec[q & 1][e] = make_float4(0.5f, 0.25f, 0.01f, 0.f);
+#else
+            ec[q & 1][e] = wsilu_row_lds<R, true>(pv[q & 1][e], tab);
+#endif
         }
+#endif
     };
-    // (tried: the two operations with paired operands - t = 16 v + 128 and v * p - as packed fp32; hipcc pairs up only
+    // (tried under policy v2: the operations with paired operands as packed fp32; hipcc pairs up only
     // half of them and pays for it in v_mov / s_nop: 1 538 instead of 1 400 VALU per super-chunk)
     auto piece_poly = [&](int q) {
-        float v[4];
+#ifdef DCB_EXP_NOEPI
+        sums[q >> 2][q & 3] = pv[q & 1][0];
+        return;
+#endif
+        float acc = ev[q & 1][0] * wsilu_poly(ev[q & 1][0], ec[q & 1][0]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float f = ef[q & 1][e];
-            float pp = fmaf(ec[q & 1][e].w, f, ec[q & 1][e].z);
-            pp = fmaf(pp, f, ec[q & 1][e].y);
-            pp = fmaf(pp, f, ec[q & 1][e].x);
-            v[e] = ev[q & 1][e] * pp;
-        }
-        sums[q >> 2][q & 3] = ((v[0] + v[1]) + v[2]) + v[3];
+        for (int e = 1; e < 4; ++e) acc = fmaf(ev[q & 1][e], wsilu_poly(ev[q & 1][e], ec[q & 1][e]), acc);
+        sums[q >> 2][q & 3] = acc;
     };
     auto piece_combine = [&](half8& out) {
 #pragma unroll
@@ -879,7 +871,7 @@ dcb_core_kernel(const CoreParams p)
         // (4 values at a time: with all 8 table entries of a run in flight the 56 registers of state pushed address
         // registers of the slab walk into scratch, and every reload is an s_waitcnt vmcnt(0) = a drained prefetch)
         float4v dlo, dhi;
-        float dv[8], df[4];
+        float dv[8];
         float4 dc[4];
         auto dc0_read = [&](int r) {
             // run r = (tile r>>1, half r&1): parked units 2 (r&1) and 2 (r&1) + 1 of that tile, half-waves paired
@@ -896,22 +888,12 @@ dcb_core_kernel(const CoreParams p)
         };
         auto dc0_index = [&](int h) {          // table entries of values 4h .. 4h+3
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = fmaf(dv[4 * h + e], 16.0f, 128.0f);
-                t = fminf(fmaxf(t, 0.0f), 255.99998f);
-                df[e] = __builtin_amdgcn_fractf(t);
-                dc[e] = tab[static_cast<int>(t) * R];
-            }
+            for (int e = 0; e < 4; ++e) dc[e] = wsilu_row_lds<R, true>(dv[4 * h + e], tab);
         };
         half8 orun;
         auto dc0_poly = [&](int r, int h) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float pp = fmaf(dc[e].w, df[e], dc[e].z);
-                pp = fmaf(pp, df[e], dc[e].y);
-                pp = fmaf(pp, df[e], dc[e].x);
-                orun[4 * h + e] = to_half(dv[4 * h + e] * pp);
-            }
+            for (int e = 0; e < 4; ++e) orun[4 * h + e] = to_half(dv[4 * h + e] * wsilu_poly(dv[4 * h + e], dc[e]));
             if (h == 1) o4[r] = orun;
         };
         auto dc0_flush = [&](int first) { EMIT_ROWS(o4, std::integral_constant<int, 64>{}, p.t1n, p.ldt1, first); };

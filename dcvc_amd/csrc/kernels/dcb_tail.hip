@@ -25,6 +25,8 @@
 #include "ops.h"
 #include "wsilu_table.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 namespace dcvc {
@@ -450,10 +452,7 @@ dcb_tail_kernel(const TailParams p)
             float sum[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float z[16];
-                wsilu16<R>(acc0[h][mt], z, tab);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) sum[h][g] = ((z[4 * g] + z[4 * g + 1]) + z[4 * g + 2]) + z[4 * g + 3];
+                wsilu_chunk16<R>(acc0[h][mt], sum[h], tab);
             }
             half8 o;
 #pragma unroll
@@ -559,7 +558,14 @@ void launch(const TailParams& p, hipStream_t stream)
                   "hipFuncSetAttribute(dcb_tail)");
     });
     const int grid = ((p.H + PH - 1) / PH) * ((p.W + PW - 1) / PW);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem_bytes, stream, p);
+    // bench.py's roofline pass: [dc.0] + dc.3 + ffn.0 + ffn.2 as one record (family 2 in bits 28..30, ops.h)
+    hipEvent_t ev0, ev1;
+    const int kflop = (DC0 ? p.CD : 0) + p.CD + 5 * p.CF;
+    if (gemm_profile_slot(GemmLaunchInfo{p.H * p.W, C, kflop, 0x20000000, 0.f}, &ev0, &ev1)) {
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem_bytes, stream, ev0, ev1, 0, p);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem_bytes, stream, p);
+    }
     hip_check(hipGetLastError(), "dcb_tail launch");
 }
 

@@ -38,7 +38,8 @@ struct GemmLaunchInfo {
 size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap);
 // Other contraction kernels (dcb_core.hip) register their launches in the same list: when profiling
 // is on, reserves a record and hands out the two events hipExtLaunchKernelGGL stamps; false = off.
-// info.K is chosen such that 2 * M * N * K is the launch's FLOP count; variant bit 31 marks dcb_core.
+// info.K is chosen such that 2 * M * N * K is the launch's FLOP count; variant bits 28..31 name the kernel
+// family: 0 conv_gemm, 8 (bit 31) dcb_core, 2 dcb_tail, 3 ffn_fused, 4 prior_chain.
 bool gemm_profile_slot(const GemmLaunchInfo& info, hipEvent_t* start, hipEvent_t* stop);
 // Tuning aid: when non-null, wave 0 of every workgroup of the following contraction launches
 // writes up to 16 shader-clock stamps (kernel entry, prologue issued, start of k-steps 0..7, main

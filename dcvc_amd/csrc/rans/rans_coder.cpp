@@ -258,7 +258,12 @@ inline void cpu_relax()
 
 WorkerPool::WorkerPool(int threads)
 {
+    // Wake-up latency of a sleeping worker (50-100 us) is the size of a whole entropy call, so workers stay hot for a
+    // while after a run. Bounded on purpose: only the first DCVC_RANS_SPIN_WORKERS (default 4)
+    // workers spin for the full DCVC_RANS_SPIN_US (default 1000 us = the distance between the 4-5 entropy calls of a
+    // picture); the others give up after 100 us, so a node with one codec per GPU burns at most 4 cores per rank.
     if (const char* e = getenv("DCVC_RANS_SPIN_US")) m_spin_us = atoi(e);
+    if (const char* e = getenv("DCVC_RANS_SPIN_WORKERS")) m_spin_workers = atoi(e);
     for (int i = 0; i < threads; ++i) {
         m_threads.emplace_back(&WorkerPool::loop, this, i);
     }
@@ -276,8 +281,9 @@ WorkerPool::~WorkerPool()
     }
 }
 
-void WorkerPool::loop(int)
+void WorkerPool::loop(int index)
 {
+    const int spin_us = index < m_spin_workers ? m_spin_us : std::min(m_spin_us, 100);
     uint64_t seen = 0;
     std::unique_lock<std::mutex> lk(m_mu);
     for (;;) {
@@ -305,10 +311,10 @@ void WorkerPool::loop(int)
             }
         }
         seen = m_epoch;
-        if (m_spin_us > 0 && !m_stop) {
+        if (spin_us > 0 && !m_stop) {
             // stay hot for a while: the next run() of the same picture is usually close
             lk.unlock();
-            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(m_spin_us);
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
             while (m_epoch_hint.load(std::memory_order_acquire) == seen) {
                 for (int i = 0; i < 64; ++i) cpu_relax();
                 if (std::chrono::steady_clock::now() >= until) break;

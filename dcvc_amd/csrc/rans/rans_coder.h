@@ -68,6 +68,7 @@ private:
     std::atomic<uint64_t> m_epoch_hint{0};
     std::atomic<int> m_pending_hint{0};
     int m_spin_us = 1000;              // DCVC_RANS_SPIN_US; 0 = always sleep
+    int m_spin_workers = 4;            // DCVC_RANS_SPIN_WORKERS: workers that spin that long (the rest: <= 100 us)
     std::exception_ptr m_error, m_local_error;      // first failure of a run(), rethrown by run()
     std::mutex m_err_mu;
 };

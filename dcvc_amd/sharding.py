@@ -114,35 +114,68 @@ def head_mask(rank, world):
 
 def decompress_fanout(proxy, bit_stream, qp, height, width, ec_parallel, reset, dist, src=0):
     """One chunk of an HT stream decoded over all ranks of `dist`. `bit_stream` etc. are needed on
-    rank `src` only. Returns this rank's {picture index: x_hat tensor}."""
+    rank `src` only. Returns this rank's {picture index: x_hat tensor}.
+
+    Rank `src` decodes WITHOUT its reconstruction heads (recon mask 0: entropy decoding, priors, decoder),
+    exports feature_p, starts the broadcast asynchronously (RCCL runs it on its own stream) and only then
+    runs its own heads - so the transfer and the other ranks' heads overlap the owner's heads instead of
+    waiting for them. The recon mask of the owner's proxy stays 0 afterwards (switching it re-captures the
+    decode graphs): call restore_heads(proxy) before using that proxy for a plain decompress() again."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    if world > 8:
+        raise ValueError("recon-head fan-out: a chunk has 8 pictures, at most 8 ranks can take part")
     mask = head_mask((rank - src) % world, world)
     if rank == src:
-        proxy.set_recon_mask(mask)
-        out = proxy.decompress(bit_stream, qp, height, width, ec_parallel, reset)
+        proxy.set_recon_mask(0)
+        proxy.decompress(bit_stream, qp, height, width, ec_parallel, reset)
         feature = proxy.export_feature()
+        work = dist.broadcast(feature, src, async_op=True) if world > 1 else None
+        out = proxy.run_recon_heads(mask, height, width)
+        if work is not None:
+            work.wait()                  # `feature` must outlive the transfer; the heads above did not wait for it
     else:
         h8, w8 = (height + 15) // 16 * 2, (width + 15) // 16 * 2
         feature = torch.empty(h8 * w8 * 512, dtype=torch.float16, device=_device_for(dist))
-    if world > 1:
         dist.broadcast(feature, src)
-    if rank != src:
         proxy.import_feature(feature, height, width)
         out = proxy.run_recon_heads(mask, height, width)
     return {i: out[i] for i in range(8) if mask >> i & 1}
 
 
-def gather_pictures(mine, dist, dst=0):
-    """{picture: [1, 3, H, W] tensor} of every rank -> on rank `dst` the 8 pictures in display order."""
-    world = dist.get_world_size()
+def restore_heads(proxy):
+    """After decompress_fanout: decompress() of this proxy runs all 8 reconstruction heads again."""
+    proxy.set_recon_mask(0xFF)
+
+
+def gather_pictures(mine, dist, dst=0, src=0, shape=None, dtype=torch.float16, device=None):
+    """{picture: [1, 3, H, W] tensor} of every rank -> on rank `dst` the 8 pictures in display order (None
+    elsewhere). Point-to-point: every picture travels once, from the rank that reconstructed it
+    (head_owner, relative to the fan-out's `src`) to `dst`. `shape` / `dtype` / `device` describe a picture
+    for a `dst` that owns none itself; by default they are taken from one of its own."""
+    world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return [mine[i] for i in range(8)]
-    any_t = next(iter(mine.values()))
-    buf = torch.zeros((8,) + tuple(any_t.shape[1:]), dtype=any_t.dtype, device=any_t.device)
-    for i, t in mine.items():
-        buf[i] = t[0]
-    dist.reduce(buf, dst, op=dist.ReduceOp.SUM)          # every picture is non-zero on exactly one rank
-    return [buf[i:i + 1] for i in range(8)] if dist.get_rank() == dst else None
+    if rank != dst:
+        reqs = [dist.isend(mine[i].contiguous(), dst) for i in sorted(mine)]
+        for r in reqs:
+            r.wait()
+        return None
+    if shape is None:
+        if not mine:
+            raise ValueError("gather_pictures: rank %d owns no picture - pass shape / dtype / device" % rank)
+        any_t = next(iter(mine.values()))
+        shape, dtype, device = tuple(any_t.shape), any_t.dtype, any_t.device
+    out, reqs = [None] * 8, []
+    for i in range(8):
+        owner = (head_owner(i, world) + src) % world
+        if owner == dst:
+            out[i] = mine[i]
+        else:
+            out[i] = torch.empty(shape, dtype=dtype, device=device if device is not None else _device_for(dist))
+            reqs.append(dist.irecv(out[i], owner))
+    for r in reqs:
+        r.wait()
+    return out
 
 
 # ------------------------------------------------------------------ GOP hand-off between GPUs

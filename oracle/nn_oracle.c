@@ -118,23 +118,37 @@ void orc_float_to_half(const float* in, uint16_t* out, int64_t n)
 }
 
 /* ------------------------------------------------------------------ WSiLU (arith.h restated) */
-/* v * sigma4(v), sigma4 = sigmoid(4 v) as the piecewise cubic of tools/gen_wsilu_table.py
- * (256 segments of width 1/16 on [-8, 8), max abs error 6.2e-7); only exactly rounded operations */
+/* Arithmetic policy v3: v * sigma4(v), sigma4 = sigmoid(4 v) as the piecewise quadratic IN v of
+ * tools/gen_wsilu_table.py (256 segments of width 1/32 on [-4, 4), max abs error 1.5e-6): the segment
+ * is bits(fl32(clamp(v, -4, 4 - 2^-9) + 4100))[13:6], the polynomial takes v itself (rows 0 / 255 are
+ * the constants 0 / 1); only exactly rounded operations. dcvc_amd/csrc/kernels/arith.h, operation for
+ * operation. */
 #include "wsilu_table.h"
+
+static inline float wsilu_sigma(float v)
+{
+    const float vc = fminf(fmaxf(v, -4.0f), 3.998046875f);
+    const float x = vc + 4100.0f;
+    uint32_t b;
+    const float* c;
+    memcpy(&b, &x, sizeof b);
+    c = kWsiluTable[(b >> 6) & 0xffu];
+    return fmaf(fmaf(c[2], v, c[1]), v, c[0]);
+}
 
 static inline float wsilu_spec(float v)
 {
-    float t = fmaf(v, 16.0f, 128.0f);
-    float fl, f, p;
-    const float* c;
-    t = fminf(fmaxf(t, 0.0f), 255.99998f);
-    fl = floorf(t);
-    f = t - fl;
-    c = kWsiluTable[(int)fl];
-    p = fmaf(c[3], f, c[2]);
-    p = fmaf(p, f, c[1]);
-    p = fmaf(p, f, c[0]);
-    return v * p;
+    return v * wsilu_sigma(v);
+}
+
+/* WSiLU + chunk-add of 4 adjacent channels: one fma chain (arith.h wsilu_chunk16) */
+static inline float wsilu_chunk4(const float* v)
+{
+    float s = v[0] * wsilu_sigma(v[0]);
+    s = fmaf(v[1], wsilu_sigma(v[1]), s);
+    s = fmaf(v[2], wsilu_sigma(v[2]), s);
+    s = fmaf(v[3], wsilu_sigma(v[3]), s);
+    return s;
 }
 
 void orc_wsilu(const float* in, float* out, int64_t n)
@@ -464,8 +478,10 @@ static void conv1x1_epilogue(const float* v, int p, const uint16_t* r1, int ldr1
 {
     int n;
     if (flags & ORC_CHUNK_ADD) {
+        /* with WSiLU the callers leave the raw accumulators in v: activation and sum are one fma chain */
         for (n = 0; n < N / 4; n++) {
-            const float s = ((v[4 * n] + v[4 * n + 1]) + v[4 * n + 2]) + v[4 * n + 3];
+            const float s = (flags & ORC_WSILU) ? wsilu_chunk4(v + 4 * n)
+                                                : ((v[4 * n] + v[4 * n + 1]) + v[4 * n + 2]) + v[4 * n + 3];
             y[(size_t)p * ldy + n] = float_to_half(s);
         }
     } else {
@@ -525,7 +541,7 @@ void orc_conv1x1(const uint16_t* x, int ldx, const uint16_t* w, const uint16_t* 
             for (n = 0; n < N; n += 16) {
                 dot16_avx512(v + n, wm + n, we + n, N, xm, xe, K);
             }
-            if (flags & ORC_WSILU) {
+            if ((flags & ORC_WSILU) && !(flags & ORC_CHUNK_ADD)) {
                 for (n = 0; n < N; n++) {
                     v[n] = wsilu_spec(v[n]);
                 }
@@ -559,7 +575,7 @@ void orc_conv1x1(const uint16_t* x, int ldx, const uint16_t* w, const uint16_t* 
                 acc = mfma_group(acc, wr + k, xs + k);
                 acc = mfma_group(acc, wr + k + 8, xs + k + 8);
             }
-            if (flags & ORC_WSILU) {
+            if ((flags & ORC_WSILU) && !(flags & ORC_CHUNK_ADD)) {
                 acc = wsilu_spec(acc);
             }
             v[n] = acc;

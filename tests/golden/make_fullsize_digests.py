@@ -15,7 +15,9 @@ such instead of being reported as a codec mismatch.
 
 Cases: DMCI 256x256 (BASELINE configs[0] tile), 1280x720 and 1920x1080 with
 q in {0, 32, 63} x skip_thres in {0.15, 0}; LD 1080p I + 3 P with a reset; HT-S one chunk at 720p and
-1080p; HT-L one chunk at 1080p. Existing entries are kept unless --force.
+1080p; HT-L one chunk at 1080p. Round 3: DMCI 1080p q 16 / 48, HT-L 720p, DMCI and
+one LD P picture at 3840x2160. Existing entries are kept unless --force. All digests depend on the arithmetic
+policy: round 3's policy v3 (WSiLU) regenerated every one of them.
 """
 import argparse
 import hashlib
@@ -146,6 +148,13 @@ def cases(quick):
                 name = "dmci_%dx%d_q%d_t%s" % (hw[1], hw[0], qp, thres)
                 c[name] = (lambda hw=hw, qp=qp, thres=thres: run_dmci(hw, qp, thres, decode=(qp == 32)))
     if not quick:
+        # round 3: the two remaining rate points bench.py cycles through (q 16, 48), an HT-L case below 1080p, and
+        # 3840x2160 (BASELINE configs[4]; README.md:202 lists it as a tuned size) - intra and one LD P picture
+        for qp in (16, 48):
+            c["dmci_1920x1080_q%d_t0.15" % qp] = (lambda qp=qp: run_dmci((1080, 1920), qp, 0.15, decode=False))
+        c["htl_1280x720"] = lambda: run_inter("htl", (720, 1280), [(32, 0)], 0.15)
+        c["dmci_3840x2160_q32_t0.15"] = lambda: run_dmci((2160, 3840), 32, 0.15, decode=False)
+        c["ld_3840x2160"] = lambda: run_inter("ld", (2160, 3840), [(32, 0)], 0.15)
         c["ld_1920x1080"] = lambda: run_inter("ld", (1080, 1920), [(32, 0), (40, 1), (40, 0)], 0.15)
         c["hts_1920x1080"] = lambda: run_inter("hts", (1080, 1920), [(32, 0)], 0.15)
         c["htl_1920x1080"] = lambda: run_inter("htl", (1080, 1920), [(32, 0)], 0.15)

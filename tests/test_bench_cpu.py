@@ -3,6 +3,8 @@ kernel stamps) are replaced by stand-ins, everything else - argument handling, t
 the separate encode / decode timing pass, the other-workload runs, the fields of the one JSON line
 the driver parses - is the real code."""
 import json
+import os
+import subprocess
 import sys
 import time
 
@@ -36,14 +38,26 @@ class _FakeNet:
         return (-w) % p, (-h) % p
 
 
+class _FakePicture:
+    """stands in for a [1, 3, H, W] device tensor: the workloads only look at its shape"""
+
+    def __init__(self, height, width):
+        self.shape = (1, 3, height, width)
+
+
 class _FakeWork:
     kind, default_graphs = "intra", True
     made = []
+
+    height, width = 1080, 1920
 
     def __init__(self, *a, **k):
         self.frames = 1
         type(self).made.append(self)
         self.calls = []
+        for arg in a:                     # the picture list, if the caller passed one
+            if isinstance(arg, list) and arg and isinstance(arg[0], _FakePicture):
+                self.height, self.width = arg[0].shape[2], arg[0].shape[3]
 
     def prepare(self, i):
         pass
@@ -64,7 +78,7 @@ class _FakeWork:
 
 class _FakeInter(_FakeWork):
     def __init__(self, kind, *a, **k):
-        super().__init__()
+        super().__init__(*a, **k)
         self.kind = kind
         self.frames = 1 if kind == "ld" else 8
 
@@ -82,11 +96,12 @@ def fake_gpu(monkeypatch):
     monkeypatch.setattr(__graft_entry__, "build", lambda: None)
     monkeypatch.setattr(bench, "build_model", lambda device: (_FakeNet(), _FakeNet()))
     monkeypatch.setattr(bench, "_to_gpu", lambda net, device: _FakeNet())
-    monkeypatch.setattr(bench, "make_pictures", lambda n, rank, device: [None] * n)
+    monkeypatch.setattr(bench, "make_pictures", lambda n, rank, device, height=1080, width=1920: [_FakePicture(height, width)] * n)
     monkeypatch.setattr(bench, "IntraWorkload", _FakeWork)
     monkeypatch.setattr(bench, "InterWorkload", _FakeInter)
-    monkeypatch.setattr(bench, "roofline", lambda work: {"bound": "mfma", "achieved": 1.0, "peak": 2500.0,
-                                                        "unit": "TFLOP/s", "frac": 0.0004, "traffic": None})
+    monkeypatch.setattr(bench, "roofline", lambda work, n=5: {"bound": "mfma", "kernel": "dcb_core_kernel", "achieved": 1.0,
+                                                             "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.0004, "traffic": None,
+                                                             "all_contractions": {"achieved": 0.9, "frac": 0.00036}})
     monkeypatch.setattr(bench, "cpu_baseline", lambda net: {"value": 1e-3, "unit": "frames/s", "cores": 1,
                                                             "kind": "port", "sample": "stand-in"})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -103,11 +118,16 @@ def _run(monkeypatch, capsys, argv):
 
 
 def test_one_json_line_with_the_contract_fields(fake_gpu, monkeypatch, capsys):
-    d = _run(monkeypatch, capsys, ["--steps", "7", "--warmup", "2"])
+    d = _run(monkeypatch, capsys, ["--steps", "7", "--warmup", "2", "--min-seconds", "0.3"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "encode_fps", "decode_fps",
-                "other_workloads"):
+                "other_workloads", "sustained", "uhd"):
         assert key in d, key
+    # the K timed steps stay exactly K; the longer region behind them is reported beside, never instead
+    assert d["sustained"]["seconds"] >= 0.3 and d["sustained"]["steps"] >= 7 and d["sustained"]["value"] > 0
+    assert d["uhd"]["resolution"] == "3840x2160" and set(d["uhd"]) == {"resolution", "intra", "ld", "hts", "htl"}
+    assert d["roofline"]["kernel"] == "dcb_core_kernel" and "all_contractions" in d["roofline"]
+    assert all("roofline" in o for o in d["other_workloads"].values())
     assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f16"
     assert d["config"]["pictures_per_step"] == 1 and "workload" in d["config"] and "model" not in d["config"]
@@ -126,15 +146,37 @@ def test_one_json_line_with_the_contract_fields(fake_gpu, monkeypatch, capsys):
 
 
 def test_timed_region_runs_exactly_k_steps(fake_gpu, monkeypatch, capsys):
-    d = _run(monkeypatch, capsys, ["--steps", "5", "--warmup", "3", "--no-extras", "--no-roofline", "--no-cpu-baseline"])
+    d = _run(monkeypatch, capsys, ["--steps", "5", "--warmup", "3", "--no-extras", "--no-roofline", "--no-cpu-baseline",
+                                   "--min-seconds", "0"])
     w = _FakeWork.made[0]
     timed_and_warm = [c for c in w.calls if c[0] == "c" and c[1] < 8]
     assert len(timed_and_warm) == 8                       # 3 warm-up + 5 timed, then the per-call timing pass
-    assert "roofline" not in d and "cpu_baseline" not in d and "other_workloads" not in d
+    assert "roofline" not in d and "cpu_baseline" not in d and "other_workloads" not in d and "sustained" not in d
+
+
+def test_resolution_flag(fake_gpu, monkeypatch, capsys):
+    d = _run(monkeypatch, capsys, ["--steps", "3", "--warmup", "1", "--resolution", "3840x2160", "--no-extras",
+                                   "--no-cpu-baseline", "--min-seconds", "0"])
+    assert d["config"]["resolution"] == "3840x2160" and "3840x2160" in d["metric"] and "uhd" not in d
+    assert _FakeWork.made[0].height == 2160 and _FakeWork.made[0].width == 3840
+    assert d["bpp"] == pytest.approx(8.0 * 1000 / (3840 * 2160))
+    with pytest.raises(SystemExit):
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--resolution", "1920"])
+        bench.main()
+
+
+def test_reset_cadence_of_the_inter_workloads():
+    """test_video.py:232-235 with reset_interval 32: LD resets the feature memory on every 32nd picture of a GOP,
+    the 8-picture models on every 4th chunk (frame_idx + 8) % 32 == 1."""
+    w = bench.InterWorkload.__new__(bench.InterWorkload)
+    w.frames, w.gop = 1, 96
+    assert [i for i in range(96) if w._reset(i)] == [31, 63, 95]
+    w.frames, w.gop = 8, 12
+    assert [i for i in range(24) if w._reset(i)] == [3, 7, 11, 15, 19, 23]
 
 
 def test_inter_workload_line(fake_gpu, monkeypatch, capsys):
-    d = _run(monkeypatch, capsys, ["--steps", "4", "--warmup", "1", "--workload", "hts", "--no-extras"])
+    d = _run(monkeypatch, capsys, ["--steps", "4", "--warmup", "1", "--workload", "hts", "--no-extras", "--min-seconds", "0.1"])
     assert d["config"]["pictures_per_step"] == 8 and "HT-S" in d["metric"]
     assert d["value"] == pytest.approx(8 * 4 / (d["ms_per_step"] * 4 / 1e3), rel=1e-6)
     assert "cpu_baseline" not in d                        # the CPU baseline belongs to the headline workload
@@ -178,13 +220,13 @@ def test_one_rank_of_a_two_gpu_launch(fake_gpu, monkeypatch, capsys, rank):
     monkeypatch.setenv("RANK", str(rank))
     monkeypatch.setenv("LOCAL_RANK", str(rank))
     monkeypatch.setenv("WORLD_SIZE", "2")
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-roofline"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-roofline", "--min-seconds", "0.1"])
     bench.main()
     lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
     w = _FakeWork.made[0]
     timed = [c[1] for c in w.calls if c[0] == "c"][1:5]
     assert timed == [1 + 4 * rank + i for i in range(4)]          # warm-up step 0, then this rank's share of the 8 steps
-    assert fake.barriers >= 3 and fake.reduced == 1
+    assert fake.barriers >= 3 and fake.reduced == 2          # the K timed steps and the sustained region
     if rank == 1:
         assert lines == []
         return
@@ -206,7 +248,7 @@ def test_fan_out_line(fake_gpu, monkeypatch, capsys):
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")
     monkeypatch.setenv("WORLD_SIZE", "2")
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--workload", "hts", "--fanout", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--workload", "hts", "--fanout", "--steps", "3", "--warmup", "1", "--min-seconds", "0"])
     bench.main()
     d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.strip()][0])
     assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["sharding"] == "recon-head fan-out"
@@ -215,3 +257,25 @@ def test_fan_out_line(fake_gpu, monkeypatch, capsys):
     with pytest.raises(SystemExit):
         monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "ld", "--fanout"])
         bench.main()
+
+
+@pytest.mark.timeout(300)
+def test_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver calls it): the process re-launches
+    itself under torch.distributed.run, both ranks rendezvous on 127.0.0.1, run the real main() - barriers, shard of
+    the 2 K steps, max over ranks - and rank 0 alone prints the one line with n_gpus 2. gloo + stand-in codec here;
+    on the GPU box the same path runs nccl (= RCCL)."""
+    env = dict(os.environ, DCVC_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_launch_child.py")
+    res = subprocess.run([sys.executable, child, "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-roofline", "--min-seconds", "0.2"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 4 / (d["ms_per_step"] * 4 / 1e3), rel=1e-6)
+    assert d["sustained"]["seconds"] >= 0.2
+    assert res.stderr.count("done in") == 2                # two rank processes ran main() to the end

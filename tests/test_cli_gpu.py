@@ -158,6 +158,15 @@ def test_encode_decode_files_equal_the_plugin_path(tmp_path, inter, n):
     assert log["i_frame_num"] == n_i and log["p_frame_num"] == n - n_i
     assert log["ave_all_frame_psnr"] == pytest.approx(float(np.mean(want_psnr)), abs=1e-6)
     assert log["ave_all_frame_bpp"] == pytest.approx(8.0 * len(want_bin) / (n * H * W), rel=1e-9)
+    if inter == "hts":
+        # ragged last chunk (1 + 8 + 2 pictures). Without -n the source's length trims the padding pictures - nothing
+        # of them reaches rec.yuv (one duplicate used to slip through) ...
+        r2 = run(["decode"] + args + ["-i", str(tmp_path / "out.bin"), "-o", str(tmp_path / "rec2.yuv"), "--ref", str(tmp_path / "in.yuv")])
+        assert (tmp_path / "rec2.yuv").read_bytes() == want_rec and "decoded %d pictures" % n in r2.stdout
+        # ... and with neither -n nor --ref the tool says that it cannot know and writes whole chunks
+        r3 = run(["decode"] + args + ["-i", str(tmp_path / "out.bin"), "-o", str(tmp_path / "rec3.yuv")])
+        assert "warning" in r3.stderr and len((tmp_path / "rec3.yuv").read_bytes()) == 17 * H * W * 3 // 2
+        assert (tmp_path / "rec3.yuv").read_bytes()[:len(want_rec)] == want_rec
     # the log is what the BD-rate tool reads
     from dcvc_amd import bd_rate
     assert bd_rate.curves({"seq": {"q": log}})["seq"][0][0] == log["ave_all_frame_bpp"]

@@ -217,6 +217,75 @@ def test_recon_head_fan_out_equals_one_gpu(structure):
                 assert torch.equal(got[i], want[c][i]), (world, c, i)
 
 
+class _LoopbackDist:
+    """torch.distributed of a 2-rank job played by ONE process: rank 0's broadcast parks the tensor, rank 1's picks
+    it up - enough to drive sharding.decompress_fanout itself (owner without heads -> export -> async broadcast
+    -> own heads; peer: import -> heads) on a 1-GPU box."""
+    mailbox = {}
+
+    class _Work:
+        def wait(self):
+            pass
+
+    def __init__(self, rank, world=2):
+        self.rank, self.world = rank, world
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def get_backend(self):
+        return "nccl"
+
+    def broadcast(self, t, src, async_op=False):
+        if self.rank == src:
+            type(self).mailbox["t"] = t.clone()
+        else:
+            t.copy_(type(self).mailbox["t"])
+        return self._Work() if async_op else None
+
+
+@pytest.mark.parametrize("structure", ["hts", "htl"])
+def test_decompress_fanout_runs_the_owners_heads_behind_the_export(structure):
+    """sharding.decompress_fanout as bench.py --fanout calls it: three chunks incl. a memory reset, the 8 pictures of
+    every chunk equal a plain decompress() bit for bit, the owner's temporal state carries on, and after
+    restore_heads() the owner's proxy decodes plainly again."""
+    from dcvc_amd import sharding
+    m = dmc_ht_model(structure, skip_thres=0.15)
+    hw = (96, 160)
+    sps = {"height": hw[0], "width": hw[1]}
+    ref = to_device_input(_padded(picture(*hw, index=0)))
+    enc, plain, owner, peer = _gpu_net(m), _gpu_net(m), _gpu_net(m), _gpu_net(m)
+    enc.add_ref_feature_from_frame(ref)
+    for d in (plain, owner):
+        d.add_ref_feature_from_frame(ref, apply_feature_adaptor=False)
+    pb, pr = _pads(enc, *hw)
+    po, pp = owner._ensure_proxy(), peer._ensure_proxy()
+    plan = [(20, 0), (44, 1), (30, 0), (36, 0)]
+    for i, (qp, reset) in enumerate(plan):
+        r = enc.compress(to_device_input(chunk(hw[0], hw[1], 1 + 8 * i)), qp, reset, pb, pr)
+        want = [t.clone() for t in plain.decompress(r["bit_stream"], sps, qp, r["ec_parallel"], reset)["x_hat"]]
+        torch.cuda.synchronize()
+        bits = np.frombuffer(r["bit_stream"], dtype=np.uint8)
+        if i < 3:
+            got = dict(sharding.decompress_fanout(po, bits, qp, hw[0], hw[1], r["ec_parallel"], bool(reset), _LoopbackDist(0)))
+            got = {k: v.clone() for k, v in got.items()}
+            mine = sharding.decompress_fanout(pp, None, qp, hw[0], hw[1], 0, bool(reset), _LoopbackDist(1))
+            torch.cuda.synchronize()
+            assert not set(got) & set(mine)
+            got.update(mine)
+        else:
+            sharding.restore_heads(po)
+            out = po.decompress(bits, qp, hw[0], hw[1], r["ec_parallel"], bool(reset))
+            torch.cuda.synchronize()
+            got = dict(enumerate(out))
+        assert sorted(got) == list(range(8))
+        for k in range(8):
+            assert torch.equal(got[k], want[k]), (i, k)
+
+
 def _fanout_rank(rank, world, port, structure, out_path):
     import pickle
     import torch.distributed as dist

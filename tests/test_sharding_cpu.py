@@ -127,7 +127,7 @@ class _FakeHT:
     H8, W8 = 4, 6
 
     def __init__(self):
-        self.mask, self.feature, self.decoded = 0xFF, None, 0
+        self.mask, self.feature, self.decoded, self.head_calls = 0xFF, None, 0, []
 
     def set_recon_mask(self, mask):
         self.mask = mask
@@ -140,6 +140,7 @@ class _FakeHT:
         self.decoded += 1
         g = torch.Generator().manual_seed(len(bit_stream) + qp)
         self.feature = torch.randn(self.H8 * self.W8 * 512, generator=g).half()
+        self.head_calls.append((self.mask, "decompress"))
         return self._heads(self.mask)
 
     def export_feature(self):
@@ -149,6 +150,7 @@ class _FakeHT:
         self.feature = feature.clone()
 
     def run_recon_heads(self, mask, height, width):
+        self.head_calls.append((mask, "run_recon_heads"))
         return self._heads(mask)
 
 
@@ -162,6 +164,11 @@ def _fanout_worker(rank, world, port, out_path):
         mine = sharding.decompress_fanout(p, b"x" * 77 if rank == 0 else None, 30, 32, 48, 1, False, dist)
         assert set(mine) == {i for i in range(8) if sharding.head_owner(i, world) == rank}
         assert p.decoded == (1 if rank == 0 else 0), "only the owner of the stream touches the bytes"
+        if rank == 0:
+            # the owner decodes WITHOUT heads (they run behind the start of the broadcast) and says so
+            assert p.mask == 0 and p.head_calls == [(0, "decompress"), (sharding.head_mask(0, world), "run_recon_heads")]
+            sharding.restore_heads(p)
+            assert p.mask == 0xFF
         pics = sharding.gather_pictures(mine, dist)
         if rank == 0:
             with open(out_path, "wb") as f:
@@ -183,3 +190,32 @@ def test_recon_head_fan_out_over_two_ranks(tmp_path):
     ref = _FakeHT()
     want = [t.numpy().tobytes() for t in ref.decompress(b"x" * 77, 30, 32, 48, 1, False)]
     assert got == want
+
+
+class _NineRanks:
+    def get_rank(self):
+        return 0
+
+    def get_world_size(self):
+        return 9
+
+
+def test_fan_out_rejects_more_ranks_than_pictures():
+    with pytest.raises(ValueError, match="at most 8 ranks"):
+        sharding.decompress_fanout(_FakeHT(), b"x", 30, 32, 48, 1, False, _NineRanks())
+
+
+class _Solo:
+    """a rank that reconstructed nothing (cannot happen with <= 8 ranks; the error must still be a clean one, not a
+    StopIteration with the other ranks hanging in a collective - ADVICE round 2)"""
+
+    def get_world_size(self):
+        return 3
+
+    def get_rank(self):
+        return 2
+
+
+def test_gather_needs_a_shape_when_the_collector_owns_nothing():
+    with pytest.raises(ValueError, match="owns no picture"):
+        sharding.gather_pictures({}, _Solo(), dst=2)

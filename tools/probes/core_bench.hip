@@ -1,0 +1,185 @@
+// core_bench - A/B timing of the block kernels of several builds of libdcvc_amd.so in ONE process, without
+// Python (a fresh GPU box spends 1-2 minutes in `import torch`; this starts at once).
+//
+//   core_bench [-p pixels] [-r rounds] [-n launches] lib_a.so [lib_b.so ...]
+//
+// Every library is dlopen()ed privately; per round and library: n launches of dcvc_dcb_core (with and without the
+// next block's dc.0) and of the 4-launch conv1x1 sequence it replaces, bracketed by HIP events on one stream. Rounds are
+// interleaved over the libraries (drift, DVFS). Operands: uniform random fp16 (never zeros: a zero-filled matrix
+// core clocks 15-20 % higher). Prints per library the median microseconds, TFLOP/s, a checksum of y, and the in-kernel
+// timeline of dcb_core (shader-clock stamps per phase, median over workgroups).
+//
+// build: hipcc -O2 --offload-arch=gfx950 tools/probes/core_bench.hip -o tools/_bin/core_bench -ldl
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#define OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); exit(1); } } while (0)
+
+typedef int (*core_fn)(const void*, int, const void*, int, const void*, const void*, const void*, const void*, const void*,
+                       const void*, const void*, const void*, const void*, const void*, void*, int, void*, int, int, int, int, void*);
+typedef int (*conv_fn)(const void*, int, const void*, const void*, const void*, int, const void*, int, const void*, const void*,
+                       void*, int, int, int, int, int, void*);
+typedef int (*dw_fn)(const void*, int, const void*, void*, int, int, int, int, void*);
+typedef int (*tl_fn)(void*);
+typedef const char* (*err_fn)(void);
+
+struct Lib {
+    std::string path;
+    void* h = nullptr;
+    core_fn core = nullptr;
+    conv_fn conv = nullptr;
+    dw_fn dw = nullptr;
+    tl_fn tl = nullptr;
+    err_fn err = nullptr;
+    std::vector<float> us_core, us_core_next, us_seq, us_dw;
+};
+
+static uint16_t f2h(float f)
+{
+    _Float16 h = static_cast<_Float16>(f);
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+static void* device_random(size_t n, float scale, std::mt19937& rng)
+{
+    std::vector<uint16_t> host(n);
+    std::uniform_real_distribution<float> d(-scale, scale);
+    for (auto& v : host) v = f2h(d(rng));
+    void* p = nullptr;
+    OK(hipMalloc(&p, n * 2));
+    OK(hipMemcpy(p, host.data(), n * 2, hipMemcpyHostToDevice));
+    return p;
+}
+
+static float median(std::vector<float> v)
+{
+    std::sort(v.begin(), v.end());
+    return v.empty() ? 0.f : v[v.size() / 2];
+}
+
+int main(int argc, char** argv)
+{
+    int P = 32640, rounds = 5, n = 20, H = 136, W = 240;
+    std::vector<Lib> libs;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-p") && i + 1 < argc) { P = atoi(argv[++i]); H = 1; W = P; }
+        else if (!strcmp(argv[i], "-r") && i + 1 < argc) rounds = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-n") && i + 1 < argc) n = atoi(argv[++i]);
+        else { Lib l; l.path = argv[i]; libs.push_back(l); }
+    }
+    if (libs.empty()) { fprintf(stderr, "usage: core_bench [-p pixels] [-r rounds] [-n launches] lib.so ...\n"); return 2; }
+    for (auto& l : libs) {
+        l.h = dlopen(l.path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", l.path.c_str(), dlerror()); return 1; }
+        l.core = reinterpret_cast<core_fn>(dlsym(l.h, "dcvc_dcb_core"));
+        l.conv = reinterpret_cast<conv_fn>(dlsym(l.h, "dcvc_conv1x1"));
+        l.dw = reinterpret_cast<dw_fn>(dlsym(l.h, "dcvc_dwconv3x3"));
+        l.tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_core_timeline_buffer"));
+        l.err = reinterpret_cast<err_fn>(dlsym(l.h, "dcvc_last_error"));
+        if (!l.core || !l.conv || !l.err) { fprintf(stderr, "%s: missing symbols\n", l.path.c_str()); return 1; }
+    }
+    const int C = 384;
+    std::mt19937 rng(1234);
+    const float ws = 1.7f / sqrtf(static_cast<float>(C));       // keeps activations O(1) through the block
+    void* x = device_random(static_cast<size_t>(P) * C, 1.0f, rng);
+    void* t2 = device_random(static_cast<size_t>(P) * C, 1.0f, rng);
+    void* w3 = device_random(static_cast<size_t>(C) * C, ws, rng);
+    void* w2 = device_random(static_cast<size_t>(C) * C, ws, rng);
+    void* w1 = device_random(static_cast<size_t>(C) * C, ws, rng);
+    void* w0 = device_random(static_cast<size_t>(4) * C * C, ws, rng);
+    void* wd = device_random(static_cast<size_t>(9) * C, 0.3f, rng);
+    void* b3 = device_random(C, 0.5f, rng);
+    void* b2 = device_random(C, 0.5f, rng);
+    void* b1 = device_random(C, 0.5f, rng);
+    void* b0 = device_random(4 * C, 0.5f, rng);
+    void *y, *t1, *y1, *t;
+    for (void** p : {&y, &t1, &y1, &t}) { OK(hipMalloc(p, static_cast<size_t>(P) * C * 2)); OK(hipMemset(*p, 0, static_cast<size_t>(P) * C * 2)); }
+    hipStream_t st;
+    OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1;
+    OK(hipEventCreate(&e0));
+    OK(hipEventCreate(&e1));
+    auto chk = [&](const Lib& l, int rc, const char* what) { if (rc < 0) { fprintf(stderr, "%s: %s: %s\n", l.path.c_str(), what, l.err()); exit(1); } };
+    auto core = [&](Lib& l, bool next) {
+        chk(l, l.core(t2, C, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, next ? w1 : nullptr, next ? b1 : nullptr, next ? t1 : nullptr, C,
+                      y, C, P, C, 0, st), "dcb_core");
+    };
+    auto seq = [&](Lib& l) {
+        chk(l, l.conv(t2, C, w3, b3, x, C, nullptr, 0, nullptr, nullptr, y1, C, P, C, C, 0, st), "conv");
+        chk(l, l.conv(y1, C, w0, b0, nullptr, 0, nullptr, 0, nullptr, nullptr, t, C, P, C, 4 * C, 3, st), "conv");
+        chk(l, l.conv(t, C, w2, b2, y1, C, nullptr, 0, nullptr, nullptr, y, C, P, C, C, 0, st), "conv");
+        chk(l, l.conv(y, C, w1, b1, nullptr, 0, nullptr, 0, nullptr, nullptr, t1, C, P, C, C, 1, st), "conv");
+    };
+    auto timed = [&](auto&& fn) {
+        for (int i = 0; i < 3; ++i) fn();
+        OK(hipStreamSynchronize(st));
+        OK(hipEventRecord(e0, st));
+        for (int i = 0; i < n; ++i) fn();
+        OK(hipEventRecord(e1, st));
+        OK(hipEventSynchronize(e1));
+        float ms = 0;
+        OK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3f / n;
+    };
+    for (int r = 0; r < rounds; ++r) {
+        for (auto& l : libs) {
+            l.us_core_next.push_back(timed([&] { core(l, true); }));
+            l.us_core.push_back(timed([&] { core(l, false); }));
+            l.us_seq.push_back(timed([&] { seq(l); }));
+            if (l.dw && H > 1) l.us_dw.push_back(timed([&] { chk(l, l.dw(x, C, wd, t, C, H, W, C, st), "dwconv"); }));
+        }
+    }
+    const double flop = 2.0 * P * 7 * C * C;
+    std::vector<uint16_t> hy(static_cast<size_t>(P) * C);
+    for (auto& l : libs) {
+        core(l, true);
+        OK(hipStreamSynchronize(st));
+        OK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost));
+        uint64_t sum = 0;
+        for (size_t i = 0; i < hy.size(); ++i) sum = sum * 1315423911u + hy[i];
+        OK(hipMemcpy(hy.data(), t1, hy.size() * 2, hipMemcpyDeviceToHost));
+        uint64_t sum1 = 0;
+        for (size_t i = 0; i < hy.size(); ++i) sum1 = sum1 * 1315423911u + hy[i];
+        const float a = median(l.us_core_next), b = median(l.us_core), c = median(l.us_seq);
+        printf("%s\n  dcb_core + next dc.0 %7.1f us %6.0f TFLOP/s | dcb_core %7.1f us %6.0f TFLOP/s | 4 conv1x1 %7.1f us %6.0f TFLOP/s | dw3x3 %6.1f us"
+               " | y %016llx t1 %016llx\n", l.path.c_str(), a, flop / a / 1e6, b, flop * 6 / 7 / b / 1e6, c, flop / c / 1e6, median(l.us_dw),
+               static_cast<unsigned long long>(sum), static_cast<unsigned long long>(sum1));
+        if (l.tl) {
+            long long* tl = nullptr;
+            const size_t rows = 1024;
+            OK(hipMalloc(&tl, rows * 64 * 8));
+            OK(hipMemset(tl, 0, rows * 64 * 8));
+            chk(l, l.tl(tl), "timeline");
+            core(l, true);
+            OK(hipStreamSynchronize(st));
+            chk(l, l.tl(nullptr), "timeline");
+            std::vector<long long> h(rows * 64);
+            OK(hipMemcpy(h.data(), tl, rows * 64 * 8, hipMemcpyDeviceToHost));
+            OK(hipFree(tl));
+            static const char* names[11] = {"dc.3 (18 slabs)", "y1 epilogue", "ffn sc0 (12)", "ffn sc1 (15)", "ffn sc2 (15)", "ffn sc3 (15)",
+                                             "ffn sc4 (15)", "ffn sc5 (15)", "last pair + ffn.2 (3)", "y epilogue + stores", "next dc.0 (18) + drain"};
+            printf("  timeline (median cycles over workgroups):");
+            for (int i = 0; i < 11; ++i) {
+                std::vector<float> d;
+                for (size_t w = 0; w < rows; ++w) if (h[w * 64] != 0) d.push_back(static_cast<float>(h[w * 64 + i + 1] - h[w * 64 + i]));
+                printf(" %s %.0f |", names[i], median(d));
+            }
+            std::vector<float> tot;
+            for (size_t w = 0; w < rows; ++w) if (h[w * 64] != 0) tot.push_back(static_cast<float>(h[w * 64 + 11] - h[w * 64]));
+            printf(" total %.0f\n", median(tot));
+        }
+    }
+    return 0;
+}
