@@ -87,6 +87,8 @@ struct DcbW {
     bool has_adaptor = false;
     Conv1x1W adaptor, dc0, dc3, ffn0, ffn2;
     half_t* dw = nullptr;   // [9][cdc]
+    half_t* packed_main = nullptr;   // dcb_nsplit.hip weight streams (full-width blocks of width 384 / 512)
+    half_t* packed_dc0 = nullptr;
     int c = 0;              // block width (output channels)
     int cdc = 0;            // depthwise width (c or c/2)
     int cffn = 0;           // ffn inner width after chunk-add (c or c/2)
@@ -102,7 +104,8 @@ struct DcbW {
     void forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut = false,
                  const half_t* q_fused = nullptr, const half_t* q_after = nullptr, View alt = View(),
                  const DcbW* next = nullptr, bool dc0_done = false) const;
-    bool core_fused() const;                     // this block runs through dcb_core
+    bool core_fused() const;                     // this block runs through dcb_core / dcb_nsplit
+    bool nsplit() const { return packed_main != nullptr; }
     bool feeds(const DcbW& next) const;          // ... and can compute next's dc.0 on the way out
 };
 

@@ -159,16 +159,24 @@ void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
     if (dc3.cin != cdc || dc3.cout != c || ffn0.cin != c || ffn2.cin != cffn || ffn2.cout != c) {
         throw std::invalid_argument("inconsistent DepthConvBlock shapes under " + p);
     }
+    if (dcb_nsplit_supported(c, cdc, cffn) && dc0.b && dc3.b && ffn0.b && ffn2.b) {
+        // kernels/dcb_nsplit.hip: per-wave linear streams of MFMA weight fragments, packed once on the device
+        packed_main = mem.alloc_half(dcb_nsplit_main_halves(c));
+        packed_dc0 = mem.alloc_half(dcb_nsplit_dc0_halves(c));
+        dcb_nsplit_pack_main(dc3.w, ffn0.w, ffn2.w, c, packed_main, nullptr);
+        dcb_nsplit_pack_dc0(dc0.w, c, packed_dc0, nullptr);
+        hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(pack)");
+    }
 }
 
 bool DcbW::core_fused() const
 {
-    return dcb_core_supported(c, cdc, cffn) && dc0.b && dc3.b && ffn0.b && ffn2.b;
+    return nsplit() || (dcb_core_supported(c, cdc, cffn) && dc0.b && dc3.b && ffn0.b && ffn2.b);
 }
 
 bool DcbW::feeds(const DcbW& next) const
 {
-    return core_fused() && next.core_fused() && !next.has_adaptor;
+    return core_fused() && next.core_fused() && !next.has_adaptor && next.c == c && nsplit() == next.nsplit();
 }
 
 void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut,
@@ -217,6 +225,18 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         return;
     }
     dwconv3x3(s.t1, cdc, dw, s.t2, cdc, H, W, cdc, st);
+    if (nsplit()) {
+        // dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) in one launch, activations in LDS, weights per wave from L2
+        DcbNsplitDesc d;
+        d.t2 = s.t2; d.ldt = cdc; d.x = in.p; d.ldx = in.ld;
+        d.wmain = packed_main; d.b3 = dc3.b; d.b0 = ffn0.b; d.b2 = ffn2.b;
+        d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.shortcut = shortcut;
+        if (next != nullptr) {
+            d.wnext = next->packed_dc0; d.b1n = next->dc0.b; d.t1n = s.t1; d.ldt1 = next->cdc;
+        }
+        dcb_nsplit(d, st);
+        return;
+    }
     if (core_fused()) {
         // dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) in one launch, intermediates in registers
         DcbCoreDesc d;

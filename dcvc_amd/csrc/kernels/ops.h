@@ -39,7 +39,7 @@ size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap);
 // Other contraction kernels (dcb_core.hip) register their launches in the same list: when profiling
 // is on, reserves a record and hands out the two events hipExtLaunchKernelGGL stamps; false = off.
 // info.K is chosen such that 2 * M * N * K is the launch's FLOP count; variant bits 28..31 name the kernel
-// family: 0 conv_gemm, 8 (bit 31) dcb_core, 2 dcb_tail, 3 ffn_fused, 4 prior_chain.
+// family: 0 conv_gemm, 8 (bit 31) dcb_core, 2 dcb_tail, 3 ffn_fused, 4 dcb_nsplit.
 bool gemm_profile_slot(const GemmLaunchInfo& info, hipEvent_t* start, hipEvent_t* stop);
 // Tuning aid: when non-null, wave 0 of every workgroup of the following contraction launches
 // writes up to 16 shader-clock stamps (kernel entry, prologue issued, start of k-steps 0..7, main
@@ -81,6 +81,29 @@ struct DcbCoreDesc {
 bool dcb_core_supported(int c, int cdc, int cffn);
 void dcb_core_timeline_buffer(long long* device_buffer);     // tuning aid: [workgroups][64] shader-clock stamps
 void dcb_core(const DcbCoreDesc& d, hipStream_t stream);
+
+// The same block in "N-split" form (dcb_nsplit.hip, round 3): activations in LDS, every wave owns a quarter of
+// the output channels and streams ITS weight fragments straight from L2 out of a pre-packed per-wave stream
+// (dcb_nsplit_pack_main / _dc0, packed once at set_param time). c in {384, 512}. Bit-identical to dcb_core and to
+// the launch sequence. y may alias x (a workgroup reads and writes only its own pixels).
+struct DcbNsplitDesc {
+    const half_t* t2 = nullptr; int ldt = 0;
+    const half_t* x = nullptr; int ldx = 0;
+    const half_t* wmain = nullptr;              // packed dc.3 | ffn.0 | ffn.2 (dcb_nsplit_main_halves(c) halves)
+    const half_t* wnext = nullptr;              // packed dc.0 of the NEXT block (dcb_nsplit_dc0_halves(c)) or null
+    const half_t* b3 = nullptr; const half_t* b0 = nullptr; const half_t* b2 = nullptr; const half_t* b1n = nullptr;
+    const half_t* q = nullptr; const half_t* q2 = nullptr;
+    half_t* t1n = nullptr; int ldt1 = 0;
+    half_t* y = nullptr; int ldy = 0;
+    int pixels = 0, c = 0;
+    bool shortcut = false;
+};
+bool dcb_nsplit_supported(int c, int cdc, int cffn);          // DCVC_NSPLIT=0 switches it off (A/B)
+size_t dcb_nsplit_main_halves(int c);
+size_t dcb_nsplit_dc0_halves(int c);
+void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, int c, half_t* out, hipStream_t stream);
+void dcb_nsplit_pack_dc0(const half_t* w1, int c, half_t* out, hipStream_t stream);
+void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream);
 
 struct ConvKxKDesc {
     const half_t* x = nullptr; int ldx = 0;     // [in_h][in_w][ldx]

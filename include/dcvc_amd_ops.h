@@ -82,6 +82,15 @@ int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w
                   const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
                   int pixels, int c, int shortcut, void* stream);
 
+/* The same operator, same arguments, through the N-split kernel (round 3: activations in LDS, every wave owns a quarter
+ * of the output channels and streams its weight fragments from a packed copy of w3 | w0 | w2 [| w1n] that this entry point
+ * builds on first use and caches per weight pointer - the codecs pack once at set_param time). c in {384, 512}.
+ * Bit-identical to dcvc_dcb_core and to the separate launches. */
+int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
+                    const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                    const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
+                    int pixels, int c, int shortcut, void* stream);
+
 /* DepthConvBlockProxy::forward behind dc.0 (layers_proxy.cpp:79-98: d3x3, conv1x1_bias_shortcut,
  * conv1x1_bias_wsilu_chunk_add, conv1x1_bias_shortcut[2][_with_quant]) in one launch for the
  * half-width blocks of the inter models: t = dc.0 output [H*W][ldt]; dw = [9][cdc] tap-major depthwise

@@ -140,3 +140,19 @@ def test_inter_matches_oracle_digest(name):
               else from_device_output(xd))
         assert sha(xd) == c["x_hat"], "call %d: reconstruction differs from the oracle's" % i
         assert sha(dec.proxy.debug_read("feature_p", np.float16)) == c["feature_p"], (i, "decoder feature_p")
+
+
+@pytest.mark.timeout(900)
+def test_launch_sequence_path_matches_the_digests():
+    """The same digests with the block kernels switched off (DCVC_NO_DCB_CORE=1: every DepthConvBlock as its
+    launch sequence dc.0 | depthwise | dc.3 | ffn.0 | ffn.2 through conv_gemm): both paths are the same arithmetic,
+    operation for operation. The switch is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    if os.environ.get("DCVC_NO_DCB_CORE"):
+        pytest.skip("already the launch-sequence path")
+    env = dict(os.environ, DCVC_NO_DCB_CORE="1")
+    pick = "dmci_1920x1080_q32_t0.15 or dmci_1920x1080_q63_t0.0 or dmci_1280x720_q0_t0.15 or dmci_256x256"
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", pick,
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=850)
+    assert res.returncode == 0 and "4 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]

@@ -37,11 +37,12 @@ struct Lib {
     std::string path;
     void* h = nullptr;
     core_fn core = nullptr;
+    core_fn ns = nullptr;          // dcvc_dcb_nsplit (same signature), round 3
     conv_fn conv = nullptr;
     dw_fn dw = nullptr;
     tl_fn tl = nullptr;
     err_fn err = nullptr;
-    std::vector<float> us_core, us_core_next, us_seq, us_dw;
+    std::vector<float> us_core, us_core_next, us_seq, us_dw, us_ns, us_ns_next;
 };
 
 static uint16_t f2h(float f)
@@ -85,6 +86,7 @@ int main(int argc, char** argv)
         if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", l.path.c_str(), dlerror()); return 1; }
         l.core = reinterpret_cast<core_fn>(dlsym(l.h, "dcvc_dcb_core"));
         l.conv = reinterpret_cast<conv_fn>(dlsym(l.h, "dcvc_conv1x1"));
+        l.ns = reinterpret_cast<core_fn>(dlsym(l.h, "dcvc_dcb_nsplit"));
         l.dw = reinterpret_cast<dw_fn>(dlsym(l.h, "dcvc_dwconv3x3"));
         l.tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_core_timeline_buffer"));
         l.err = reinterpret_cast<err_fn>(dlsym(l.h, "dcvc_last_error"));
@@ -116,6 +118,10 @@ int main(int argc, char** argv)
         chk(l, l.core(t2, C, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, next ? w1 : nullptr, next ? b1 : nullptr, next ? t1 : nullptr, C,
                       y, C, P, C, 0, st), "dcb_core");
     };
+    auto nsplit = [&](Lib& l, bool next) {
+        chk(l, l.ns(t2, C, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, next ? w1 : nullptr, next ? b1 : nullptr, next ? t1 : nullptr, C,
+                    y, C, P, C, 0, st), "dcb_nsplit");
+    };
     auto seq = [&](Lib& l) {
         chk(l, l.conv(t2, C, w3, b3, x, C, nullptr, 0, nullptr, nullptr, y1, C, P, C, C, 0, st), "conv");
         chk(l, l.conv(y1, C, w0, b0, nullptr, 0, nullptr, 0, nullptr, nullptr, t, C, P, C, 4 * C, 3, st), "conv");
@@ -138,6 +144,10 @@ int main(int argc, char** argv)
             l.us_core_next.push_back(timed([&] { core(l, true); }));
             l.us_core.push_back(timed([&] { core(l, false); }));
             l.us_seq.push_back(timed([&] { seq(l); }));
+            if (l.ns) {
+                l.us_ns_next.push_back(timed([&] { nsplit(l, true); }));
+                l.us_ns.push_back(timed([&] { nsplit(l, false); }));
+            }
             if (l.dw && H > 1) l.us_dw.push_back(timed([&] { chk(l, l.dw(x, C, wd, t, C, H, W, C, st), "dwconv"); }));
         }
     }
@@ -156,6 +166,22 @@ int main(int argc, char** argv)
         printf("%s\n  dcb_core + next dc.0 %7.1f us %6.0f TFLOP/s | dcb_core %7.1f us %6.0f TFLOP/s | 4 conv1x1 %7.1f us %6.0f TFLOP/s | dw3x3 %6.1f us"
                " | y %016llx t1 %016llx\n", l.path.c_str(), a, flop / a / 1e6, b, flop * 6 / 7 / b / 1e6, c, flop / c / 1e6, median(l.us_dw),
                static_cast<unsigned long long>(sum), static_cast<unsigned long long>(sum1));
+        if (l.ns) {
+            OK(hipMemset(y, 0, hy.size() * 2));
+            OK(hipMemset(t1, 0, hy.size() * 2));
+            nsplit(l, true);
+            OK(hipStreamSynchronize(st));
+            OK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost));
+            uint64_t s2 = 0;
+            for (size_t i = 0; i < hy.size(); ++i) s2 = s2 * 1315423911u + hy[i];
+            OK(hipMemcpy(hy.data(), t1, hy.size() * 2, hipMemcpyDeviceToHost));
+            uint64_t s3 = 0;
+            for (size_t i = 0; i < hy.size(); ++i) s3 = s3 * 1315423911u + hy[i];
+            const float an = median(l.us_ns_next), bn = median(l.us_ns);
+            printf("  dcb_nsplit + next dc.0 %7.1f us %6.0f TFLOP/s | dcb_nsplit %7.1f us %6.0f TFLOP/s | y %016llx t1 %016llx %s\n", an, flop / an / 1e6,
+                   bn, flop * 6 / 7 / bn / 1e6, static_cast<unsigned long long>(s2), static_cast<unsigned long long>(s3),
+                   (s2 == sum && s3 == sum1) ? "(= dcb_core)" : "(DIFFERS from dcb_core)");
+        }
         if (l.tl) {
             long long* tl = nullptr;
             const size_t rows = 1024;
