@@ -369,7 +369,7 @@ def pmc_traffic(kernel):
         return None, "no PMC pass on file (%s)" % type(e).__name__
 
 
-KERNEL_NAMES = {0: "conv_gemm_kernel", 1: "dcb_core_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "prior_chain_kernel"}
+KERNEL_NAMES = {0: "conv_gemm_kernel", 1: "dcb_core_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "dcb_nsplit_kernel"}
 
 
 def roofline(work, n=len(QPS)):
@@ -421,7 +421,7 @@ def roofline(work, n=len(QPS)):
     # in, the block output and the next block's dc.0 output out ([P8][384] fp16 each) + 2.06 MB of weights
     P8 = ((work.height + 15) // 16 * 2) * ((work.width + 15) // 16 * 2)
     core_bytes = 4 * P8 * 384 * 2 + 7 * 384 * 384 * 2
-    kernels = [k for k in (part(family == f, name, core_bytes if f == 1 else None) for f, name in KERNEL_NAMES.items()) if k]
+    kernels = [k for k in (part(family == f, name, core_bytes if f in (1, 4) else None) for f, name in KERNEL_NAMES.items()) if k]
     total_ms, total_fl = float(buf["ms"].sum()), float(flops.sum())
     dom = max(kernels, key=lambda k: k["ms_per_step"])
     traffic, source = pmc_traffic(dom["kernel"])

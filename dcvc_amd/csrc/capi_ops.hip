@@ -288,6 +288,11 @@ int dcvc_gemm_timeline_buffer(void* device_buffer)
     return dcvc::guarded([&] { dcvc::gemm_timeline_buffer(static_cast<long long*>(device_buffer)); });
 }
 
+int dcvc_dcb_nsplit_timeline_buffer(void* device_buffer)
+{
+    return dcvc::guarded([&] { dcvc::dcb_nsplit_timeline_buffer(static_cast<long long*>(device_buffer)); });
+}
+
 int dcvc_dcb_core_timeline_buffer(void* device_buffer)
 {
     return dcvc::guarded([&] { dcvc::dcb_core_timeline_buffer(static_cast<long long*>(device_buffer)); });

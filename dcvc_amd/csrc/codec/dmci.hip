@@ -171,9 +171,13 @@ void DmciCodec::run_priors_from_zhat(hipStream_t st)
     m_hdec1.forward(View(m_H1, kChZ, kChZ), View(m_H2a, kChZ, kChZ), View(m_H2, kChZ, kChZ), g.H32, g.W32, m_s, st);
     m_hdec2.forward(View(m_H2, kChZ, kChZ), View(m_HP, kChY, kChY), g.H16p, g.W16p, m_s, st);
     const View pf(m_PF, 2 * kChY, 2 * kChY);
-    m_fus[0].forward(View(m_HP, kChY, kChY), pf, g.H16p, g.W16p, m_s, st);
-    m_fus[1].forward(pf, pf, g.H16p, g.W16p, m_s, st);
-    m_fus[2].forward(pf, pf, g.H16p, g.W16p, m_s, st);
+    {   // a chain of full-width blocks: each launch also computes dc.0 of the block behind it (DcbW::feeds)
+        const DcbW* n1 = m_fus[0].feeds(m_fus[1]) ? &m_fus[1] : nullptr;
+        const DcbW* n2 = m_fus[1].feeds(m_fus[2]) ? &m_fus[2] : nullptr;
+        m_fus[0].forward(View(m_HP, kChY, kChY), pf, g.H16p, g.W16p, m_s, st, false, nullptr, nullptr, View(), n1, false);
+        m_fus[1].forward(pf, pf, g.H16p, g.W16p, m_s, st, false, nullptr, nullptr, View(), n2, n1 != nullptr);
+        m_fus[2].forward(pf, pf, g.H16p, g.W16p, m_s, st, false, nullptr, nullptr, View(), nullptr, n2 != nullptr);
+    }
     {
         Conv1x1Desc d;
         d.x = m_PF; d.ldx = 2 * kChY; d.w = m_fus3.w; d.bias = m_fus3.b;
@@ -195,8 +199,13 @@ void DmciCodec::run_spatial_prior(int k, hipStream_t st)
 {
     const Geometry& g = m_g;
     const View ad(m_AD, 2 * kChY, 2 * kChY);
-    m_sp_adaptor[k].forward(View(m_CAT, 2 * kChY, 2 * kChY), ad, g.H16, g.W16, m_s, st);
-    for (int i = 0; i < 3; ++i) m_sp[i].forward(ad, ad, g.H16, g.W16, m_s, st);
+    const DcbW* next = m_sp_adaptor[k].feeds(m_sp[0]) ? &m_sp[0] : nullptr;
+    m_sp_adaptor[k].forward(View(m_CAT, 2 * kChY, 2 * kChY), ad, g.H16, g.W16, m_s, st, false, nullptr, nullptr, View(), next, false);
+    for (int i = 0; i < 3; ++i) {
+        const bool handed = next != nullptr;
+        next = (i < 2 && m_sp[i].feeds(m_sp[i + 1])) ? &m_sp[i + 1] : nullptr;
+        m_sp[i].forward(ad, ad, g.H16, g.W16, m_s, st, false, nullptr, nullptr, View(), next, handed);
+    }
     Conv1x1Desc d;
     d.x = m_AD; d.ldx = 2 * kChY; d.w = m_sp3.w; d.bias = m_sp3.b;
     d.y = m_SP; d.ldy = 2 * kChY; d.pixels = g.P16(); d.cin = 2 * kChY; d.cout = 2 * kChY;

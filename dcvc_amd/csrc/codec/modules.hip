@@ -404,6 +404,7 @@ void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, i
     // block runs in place (the one-launch block kernel needs input != output)
     const View a = tmp, b = tmp2;
     View cur = x;
+    bool handed = false;
     for (int i = 0; i < n; ++i) {
         View out = y;
         if (i != n - 1) {
@@ -412,8 +413,10 @@ void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, i
             out = (back % 2 == 1) ? (y_is_a ? b : a) : (y_is_a ? a : b);
         }
         const View spare = (out.p == a.p) ? b : a;              // for an adaptor: neither input nor output
+        const DcbW* next = (i + 1 < n && blocks[i].feeds(blocks[i + 1])) ? &blocks[i + 1] : nullptr;
         blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr, nullptr,
-                          cur.p == spare.p ? View() : spare);
+                          cur.p == spare.p ? View() : spare, next, handed);
+        handed = next != nullptr;
         cur = out;
     }
 }

@@ -535,7 +535,7 @@ void launch_cfg(const ConvGemmParams& p, hipStream_t stream)
         }
         pf.info[pf.used] = GemmLaunchInfo{ p.M, p.N, p.K,
                                            (SPATIAL ? 1 : 0) | (ACT << 1) | (CHUNK ? 4 : 0) | (NRES << 3) |
-                                               (QUANT ? 32 : 0) | (UPSAMPLE ? 64 : 0) | (BM << 8) | (BN << 18) | (STAGES << 28) | (XDIRECT ? (1 << 30) : 0), 0.f };
+                                               (QUANT ? 32 : 0) | (UPSAMPLE ? 64 : 0) | (BM << 8) | (BN << 18), 0.f };      // bits 28..31 = kernel family (ops.h): 0 here
         hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), smem_bytes, stream, pf.events[pf.used].first,
                               pf.events[pf.used].second, 0, p);
         ++pf.used;

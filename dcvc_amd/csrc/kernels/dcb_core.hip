@@ -440,16 +440,6 @@ dcb_core_kernel(const CoreParams p)
             // MFMA behind their reads)
             LOADS_FENCE();
             const half8 b = bfrag(s);
-#ifdef DCB_EXP_STAGGER
-            // the four waves run in lockstep (one barrier per slab) and would all hand their LDS-DMA piece to the
-            // CU's one address path at the same moment: wave w issues behind its w-th MFMA of the slice instead
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], b, acc[nt], 0, 0, 0);
-                if (wave == nt) issue_part(nx, s);
-            }
-            piece(s);
-#else
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][nt], b, acc[nt], 0, 0, 0);
@@ -460,8 +450,10 @@ dcb_core_kernel(const CoreParams p)
                 SGB_DSRD(2);
                 if constexpr (valu_per_mfma > 0) SGB_VALU(valu_per_mfma);
             }
+            // (tried in round 3: every wave issuing its piece behind a different MFMA of the slice, so that the four
+            // lockstep waves do not reach the address path together - 134 instead of 101 us: the scalar branches
+            // cut the slice into four scheduling regions)
             issue_part(nx, s);
-#endif
             SLICE_FENCE();
             if (TIMELINE && fbase >= 0) fine(fbase + 2 + s);
         }
@@ -490,20 +482,9 @@ dcb_core_kernel(const CoreParams p)
             LOADS_FENCE();
             const half8 b = bfrag(s);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][0], b, acc[0], 0, 0, 0);
-#ifdef DCB_EXP_STAGGER
-            if (wave == 2 * (s & 1)) issue_part(nx, s >> 1);
-#endif
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % 3][1], b, acc[1], 0, 0, 0);
-#ifdef DCB_EXP_STAGGER
-            if (wave == 2 * (s & 1) + 1) issue_part(nx, s >> 1);
-#endif
             piece(s);
-#ifdef DCB_EXP_STAGGER
-            if (s & 1) SLICE_FENCE();
-            if (false) {
-#else
             if (s & 1) {                 // one region = two k-slices = 4 MFMAs, closed by the LDS-DMA piece
-#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     SGB_MFMA(1);

@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <stdexcept>
+#include <type_traits>
 
 namespace dcvc {
 
@@ -46,11 +47,27 @@ const float4* wsilu_table_device();      // conv_gemm.hip
 namespace {
 
 constexpr int NTHREADS = 256;
-constexpr int RING = 16;                 // weight fragments in flight per wave (4 registers each)
+#ifndef NS_RING
+#define NS_RING 16
+#endif
+constexpr int RING_DEFAULT = NS_RING;    // weight fragments in flight per wave (4 registers each)
 constexpr int R = 4;                     // interleaved copies of the WSiLU table
 constexpr int TABLE_BYTES = WSILU_SEGMENTS * 16;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N). The weight ring below is indexed ONLY through such
+// constants: with plain (later unrolled) loop counters its promotion to registers depended on the order of LLVM's
+// unroll / SROA passes and came and went with unrelated edits - 16 x 4 registers through scratch memory, every
+// access a vmcnt(0) (measured: the walk at L2 latency).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 template <int C>
 struct Geo {
@@ -75,6 +92,7 @@ struct NsParams {
     half_t* y; int ldy;
     half_t* t1n; int ldt1;
     int M, shortcut;
+    long long* timeline;      // optional [workgroups][32] shader-clock stamps of wave 0 (tools/probes/core_bench.hip)
 };
 
 // One LDS-DMA piece (64 lanes x 16 B, lane l lands at lds_dst + 16 l), wave-uniform base + 32-bit lane offset.
@@ -88,6 +106,8 @@ __global__ void __launch_bounds__(NTHREADS, 1)
 dcb_nsplit_kernel(const NsParams p)
 {
     using G = Geo<C>;
+    // 512 channels x 64 pixels: 8 accumulator tiles per layer + 8 per ffn.0 pass leave room for 8 fragments in flight
+    constexpr int RING = (C == 512 && PXT == 2) ? 8 : RING_DEFAULT;
     constexpr int PX = 32 * PXT;
     constexpr int KS = G::KS, MT = G::MT, CH = G::CH, PITCH = G::PITCH;
     constexpr int BUF = PX * PITCH;
@@ -109,9 +129,21 @@ dcb_nsplit_kernel(const NsParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 31;
     const int hi = lane >> 5;
-    const int m0 = blockIdx.x * PX;
+    const int ntiles = (p.M + PX - 1) / PX;
+    int tile = blockIdx.x;                               // persistent: tiles blockIdx.x, + gridDim.x, ...
+    int m0 = tile * PX;
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)smem));
     if ((lds_base & 16383u) != 0) __builtin_trap();      // dynamic LDS starts at 0 (no static LDS in this kernel)
+    // stamps: 0 entry | 1 tiles + constants in LDS | 2 dc.3 MFMAs | 3 dc.3 epilogue + barrier | per ffn.0 pass: MFMAs,
+    // epilogue | ffn.2 MFMAs | epilogue + barrier | y out | dc.0 MFMAs | epilogue + barrier | t1n out
+    int stamp_no = 0;
+    auto stamp = [&]() {
+        if (p.timeline != nullptr && tid == 0 && stamp_no < 32 && tile == static_cast<int>(blockIdx.x)) {
+            p.timeline[static_cast<size_t>(blockIdx.x) * 32 + stamp_no] = static_cast<long long>(__builtin_readcyclecounter());
+        }
+        ++stamp_no;
+    };
+    stamp();
 
     // ---- L2 warm-up (dcb_core.hip: every workgroup streams the SAME weights at the same time and L2 starts cold
     // at a kernel boundary; each workgroup first touches ITS share of the stream, all misses in flight together)
@@ -126,70 +158,113 @@ dcb_nsplit_kernel(const NsParams p)
         }
     }
 
-    // ---- input tiles: t2 -> A, x -> B, whole rows by LDS-DMA; LDS image lane-linear, the bank swizzle (16-byte
-    // chunk c of row r lives at chunk c ^ (r & 15)) sits on the SOURCE side
-    {
-        const int last = p.M - 1 - min(m0, p.M - 1);                  // rows behind the picture read its last row
-        const half_t* const t2w = p.t2 + static_cast<size_t>(min(m0, p.M - 1)) * p.ldt;
-        const half_t* const xw = p.x + static_cast<size_t>(min(m0, p.M - 1)) * p.ldx;
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int pos = i * NTHREADS + tid;
-            const int r = pos / CH, pc = pos % CH;
-            const int lc = pc ^ (r & 15);
-            const int rr = min(r, last);
-            const unsigned dst = (i * NTHREADS + wave * 64) * 16;
-            lds_dma16(t2w, static_cast<unsigned>(rr * p.ldt + lc * 8) * 2u, lds_base + dst);
-            lds_dma16(xw, static_cast<unsigned>(rr * p.ldx + lc * 8) * 2u, lds_base + BUF + dst);
-        }
-    }
-    // ---- constants -> LDS: WSiLU table in R interleaved copies, biases as fp32, scales as fp16
-    {
-        float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
-#pragma unroll
-        for (int k = 0; k < R * WSILU_SEGMENTS / NTHREADS; ++k) t[tid + k * NTHREADS] = p.wsilu[(tid + k * NTHREADS) / R];
-        float* lb = reinterpret_cast<float*>(smem + OFF_BIAS);
-        for (int i = tid; i < BIAS_FLOATS; i += NTHREADS) {
-            const half_t v = i < C ? p.b3[i] : i < 5 * C ? p.b0[i - C] : i < 6 * C ? p.b2[i - 5 * C]
-                           : (p.b1n != nullptr ? p.b1n[i - 6 * C] : static_cast<half_t>(0.f));
-            lb[i] = static_cast<float>(v);
-        }
-        half_t* lq = reinterpret_cast<half_t*>(smem + OFF_Q);
-        for (int i = tid; i < 2 * C; i += NTHREADS) {
-            lq[i] = i < C ? (p.q != nullptr ? p.q[i] : static_cast<half_t>(1.f)) : (p.q2 != nullptr ? p.q2[i - C] : static_cast<half_t>(1.f));
-        }
-    }
+    // ---- constants: loaded into registers FIRST (16-byte units, all loads independent). Every use of a loaded
+    // register waits for everything issued before it (vmcnt retires in order): round 3's first version read the
+    // biases one value per loop iteration behind the tile transfers - 13 dependent memory round trips, 19.6 k cycles
+    // of prologue per workgroup (profiles/r03_nsplit_ablation.txt).
+    constexpr int TAB_PER_THREAD = R * WSILU_SEGMENTS / NTHREADS;
+    static_assert(TAB_PER_THREAD == 4, "four table rows per thread, spelled out (as a loop the array went through scratch)");
+    const float4 tab0 = p.wsilu[tid / R], tab1 = p.wsilu[(tid + NTHREADS) / R], tab2 = p.wsilu[(tid + 2 * NTHREADS) / R],
+                 tab3 = p.wsilu[(tid + 3 * NTHREADS) / R];
+    constexpr int CONST_UNITS = 9 * C / 8;             // b3 | b0 (4C) | b2 | b1n | q | q2 in 8-channel units
+    constexpr int CONST_PER_THREAD = (CONST_UNITS + NTHREADS - 1) / NTHREADS;
+    static_assert(CONST_PER_THREAD <= 3, "three named registers below");
+    auto const_unit = [&](int k) {
+        const int ch = min(tid + k * NTHREADS, CONST_UNITS - 1) * 8;
+        const half_t* src = ch < C ? p.b3 + ch
+                          : ch < 5 * C ? p.b0 + (ch - C)
+                          : ch < 6 * C ? p.b2 + (ch - 5 * C)
+                          : ch < 7 * C ? (p.b1n != nullptr ? p.b1n + (ch - 6 * C) : p.b2)
+                          : ch < 8 * C ? (p.q != nullptr ? p.q + (ch - 7 * C) : p.b2)
+                          : (p.q2 != nullptr ? p.q2 + (ch - 8 * C) : p.b2);
+        return *reinterpret_cast<const half8*>(src);
+    };
+    const half8 cv0 = const_unit(0), cv1 = const_unit(1), cv2 = const_unit(CONST_PER_THREAD > 2 ? 2 : 1);
     const float* const lb3 = reinterpret_cast<const float*>(smem + OFF_BIAS);
     const float* const lb0 = lb3 + C;
     const float* const lb2 = lb3 + 5 * C;
     const float* const lb1n = lb3 + 6 * C;
     const half_t* const lq = reinterpret_cast<const half_t*>(smem + OFF_Q);
     const half_t* const lq2 = lq + C;
-    const unsigned tab = lds_base + OFF_TABLE + (lane & (R - 1)) * 16;
+    unsigned tab = lds_base + OFF_TABLE + (lane & (R - 1)) * 16;
 
     // ---- the wave's weight stream: fragment f at ws[f * 64] (one contiguous KB per fragment, lane-linear)
-    const half8* const wsm = p.wmain + static_cast<size_t>(wave) * G::F_MAIN * 64 + lane;
-    const half8* const wsn = NEXT ? p.wnext + static_cast<size_t>(wave) * G::F_DC0 * 64 + lane : nullptr;
+    // as 32-bit byte offsets from the (kernel-argument, hence provably global) stream pointers: the loads then take
+    // the scalar-base + lane-offset form of global_load. (A laundered POINTER loses its address space: flat_load, which
+    // counts on lgkmcnt as well and turns every counted wait into vmcnt(0) - measured: the walk 50 % slower.)
+    unsigned wsm = static_cast<unsigned>(wave * G::F_MAIN * 64 + lane) * 16u;
+    unsigned wsn = static_cast<unsigned>(wave * G::F_DC0 * 64 + lane) * 16u;
     // Fragment f of the stream lives in ring[f % RING] from its load (issued RING fragments ahead) to its MFMAs; every
     // index below is a function of unrolled loop counters only, so the ring is 16 x 4 named registers after unrolling.
     half8 ring[RING];
-    auto issue = [&](int f) {
-        if (f < TOTAL) {
-            ring[f % RING] = f < G::F_MAIN ? wsm[static_cast<size_t>(f) * 64] : wsn[static_cast<size_t>(f - G::F_MAIN) * 64];
+    // Ablation switches (tools/build_variant.sh; RESULTS ARE WRONG with any of them): NS_EXP_NOLOAD = no weight loads
+    // behind the first RING fragments, NS_EXP_NOEPI = ffn.0's WSiLU + chunk sum replaced by a plain conversion
+    auto issue = [&](auto f_tag) {
+        constexpr int f = decltype(f_tag)::value;
+#ifdef NS_EXP_NOLOAD
+        if constexpr (f >= RING) return;
+#endif
+        if constexpr (f < G::F_MAIN) {
+            ring[f % RING] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.wmain) + (wsm + static_cast<unsigned>(f) * 1024u));
+        } else if constexpr (f < TOTAL) {
+            ring[f % RING] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.wnext) + (wsn + static_cast<unsigned>(f - G::F_MAIN) * 1024u));
         }
     };
-    // the tiles (LDS-DMA) go first and are waited for in full; the weight prefetch starts behind them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- a [PX][C] tile of whole rows, memory -> LDS by LDS-DMA; LDS image lane-linear, the bank swizzle (16-byte
+    // chunk c of row r lives at chunk c ^ (r & 15)) sits on the SOURCE side. Rows behind the picture read its last row.
+    int tidv = tid;                  // (made opaque once per tile: see the loop head)
+    auto dma_tile = [&](const half_t* base, int ld, unsigned lds_off, int first_row) {
+        const int f = min(first_row, p.M - 1);
+        const int last = p.M - 1 - f;
+        const half_t* const w = base + static_cast<size_t>(f) * ld;
 #pragma unroll
-    for (int i = 0; i < RING; ++i) issue(i);
+        for (int i = 0; i < PIECES; ++i) {
+            const int pos = i * NTHREADS + tidv;
+            const int r = pos / CH, pc = pos % CH;
+            const int lc = pc ^ (r & 15);
+            const int rr = min(r, last);
+            lds_dma16(w, static_cast<unsigned>(rr * ld + lc * 8) * 2u, lds_base + lds_off + (i * NTHREADS + wave * 64) * 16);
+        }
+    };
+    // first tile: t2 -> A, then the first weight fragments; everything (constants included) is waited for in full
+    dma_tile(p.t2, p.ldt, 0, m0);
     __builtin_amdgcn_sched_barrier(0);
+    static_for<0, RING>([&](auto i) { issue(i); });
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
+        t[tid] = tab0; t[tid + NTHREADS] = tab1; t[tid + 2 * NTHREADS] = tab2; t[tid + 3 * NTHREADS] = tab3;
+        float* lb = reinterpret_cast<float*>(smem + OFF_BIAS);
+        half_t* lqw = reinterpret_cast<half_t*>(smem + OFF_Q);
+        auto put = [&](int k, const half8 v) {
+            const int u = tid + k * NTHREADS;
+            if (u < BIAS_FLOATS / 8) {
+                float4v lo4, hi4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo4[e] = static_cast<float>(v[e]);
+                    hi4[e] = static_cast<float>(v[4 + e]);
+                }
+                *reinterpret_cast<float4v*>(lb + u * 8) = lo4;
+                *reinterpret_cast<float4v*>(lb + u * 8 + 4) = hi4;
+            } else if (u < CONST_UNITS) {
+                *reinterpret_cast<half8*>(lqw + (u - BIAS_FLOATS / 8) * 8) = v;
+            }
+        };
+        put(0, cv0);
+        put(1, cv1);
+        if (CONST_PER_THREAD > 2) put(2, cv2);
+    }
     __syncthreads();
     if (warm == 0x9e3779b9u && p.M < 0) p.y[0] = static_cast<half_t>(0);     // never true: keeps the warm-up loads alive
+    stamp();
 
     // ---- fragment addressing. Row of pixel tile t: (32 t + px) * PITCH; chunk c of a row sits at c ^ (px & 15).
     // B fragment of k-slice ks: chunk 2 ks + hi = (2 ks) ^ hi, so the lane part of the swizzle is one constant.
-    const int s0 = (hi ^ (px & 15)) << 4;
-    const int rowoff = px * PITCH;
+    int s0 = (hi ^ (px & 15)) << 4;
+    int rowoff = px * PITCH;
+    int hi4 = 4 * hi;                 // (bias_tile)
     auto bfrag = [&](const char* buf, int t, int ks) {
         return *reinterpret_cast<const half8*>(buf + rowoff + t * (32 * PITCH) + ((ks * 32) ^ s0));
     };
@@ -199,7 +274,7 @@ dcb_nsplit_kernel(const NsParams p)
     };
     // accumulator tile (32 channels from `first`) initialised with the bias: acc[r] = channel first + 8 (r>>2) + 4 hi + (r&3)
     auto bias_tile = [&](float16v& acc, const float* bias, int first) {
-        const float* bp = bias + first + 4 * hi;
+        const float* bp = bias + first + hi4;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4v b4 = *reinterpret_cast<const float4v*>(bp + 8 * g4);
@@ -218,34 +293,69 @@ dcb_nsplit_kernel(const NsParams p)
     };
     // NT tiles x PXT pixel tiles over the KS k-slices of a C-deep contraction, activations from `in`
     // `f0` = stream index of the contraction's first fragment
-    auto contract = [&](auto nt_tag, int f0, const char* in, auto& acc) {
+    // `piece(ks)`: work of an EARLIER accumulator set (an epilogue, cut into pieces) issued beside the MFMAs of slice ks
+    auto contract = [&](auto nt_tag, auto f0_tag, const char* in, auto& acc, auto&& piece) {
         constexpr int NT = decltype(nt_tag)::value;
+        constexpr int F0 = decltype(f0_tag)::value;
         half8 b[2][PXT];              // activation fragments, read one k-slice ahead of their MFMAs
 #pragma unroll
         for (int t = 0; t < PXT; ++t) b[0][t] = bfrag(in, t, 0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
+        static_for<0, KS>([&](auto ks_tag) {
+            constexpr int ks = decltype(ks_tag)::value;
+            if constexpr (ks + 1 < KS) {
 #pragma unroll
                 for (int t = 0; t < PXT; ++t) b[(ks + 1) & 1][t] = bfrag(in, t, ks + 1);
             }
             __builtin_amdgcn_sched_barrier(0);       // ... and stay in front of this slice's MFMAs
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const half8 a = ring[(f0 + ks * NT + j) % RING];
+            static_for<0, NT>([&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                const half8 a = ring[(F0 + ks * NT + j) % RING];
 #pragma unroll
                 for (int t = 0; t < PXT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks & 1][t], acc[j][t], 0, 0, 0);
-            }
+            });
+            piece(ks);
+#ifdef NS_SGB
+            // experiment: ask for MFMA | a few VALU | a few LDS operations | MFMA ... inside the slice instead of the
+            // compiler's lumps (VALU between two MFMAs beyond ~5 operations leaves the matrix pipe idle)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) issue(f0 + ks * NT + j + RING);
+            for (int i = 0; i < NT * PXT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NS_SGB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#endif
+            static_for<0, NT>([&](auto j_tag) { issue(std::integral_constant<int, F0 + ks * NT + decltype(j_tag)::value + RING>{}); });
             // nothing crosses a k-slice: left alone, hipcc sinks every prefetch load down to the MFMA that consumes it
             // (register pressure) and waits vmcnt(0) right behind it - the whole stream then runs at L2 latency
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
     using TagMT = std::integral_constant<int, MT>;
     using Tag4 = std::integral_constant<int, 4>;
+    auto no_piece = [](int) {};
 
+    // whole rows of an LDS tile -> memory, 16 bytes per lane, consecutive lanes = consecutive chunks of a row
+    auto copy_out = [&](const char* buf, half_t* dst, int ld) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int pos = i * NTHREADS + tidv;
+            const int r = pos / CH, lc = pos % CH;
+            const half8 v = *reinterpret_cast<const half8*>(buf + r * PITCH + ((lc ^ (r & 15)) << 4));
+            if (m0 + r < p.M) store_line(dst + static_cast<size_t>(m0 + r) * ld + lc * 8, v);
+        }
+    };
+
+    // ================================================================ persistent loop over this workgroup's tiles
+    // (tile, tile + gridDim.x, ...). The constants above are loaded once; t2 of the NEXT tile travels into A while this
+    // tile's dc.0 (or its tail) runs, x of this tile into B behind dc.3's MFMAs: only the first tile's t2 is exposed
+    // (as a kernel of one tile per workgroup the prologue was 12 k of 87 k cycles, profiles/r03_nsplit_ablation.txt).
+    for (;;) {
+    // Everything the unrolled body addresses hangs off these few per-lane values. Made opaque once per tile: as loop
+    // invariants the compiler hoists EVERY derived address out of the loop (one register pair per weight fragment,
+    // one register per LDS fragment: 1 000+ values) and spills them all (measured: 1 023 spilled registers).
+    asm volatile("" : "+v"(wsm), "+v"(wsn), "+v"(tab), "+v"(s0), "+v"(rowoff), "+v"(hi4), "+v"(tidv));
+    // x -> B: B is free (first tile: untouched; later: the previous tile's row copy is behind a barrier)
+    dma_tile(p.x, p.ldx, BUF, m0);
     // ================================================================ dc.3: y1 = W3 t2 + b3' + x   (A -> B in place of x)
     {
         float16v acc[MT][PXT];
@@ -253,7 +363,13 @@ dcb_nsplit_kernel(const NsParams p)
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT + j));
-        contract(TagMT{}, 0, bufA, acc);
+        contract(TagMT{}, std::integral_constant<int, 0>{}, bufA, acc, no_piece);
+        // x: this wave's pieces are older than weight fragments it has already consumed (retired in order), the
+        // barrier covers the other waves' pieces
+        static_assert(G::F_DC3 > RING, "dc.3 must consume fragments issued behind the x transfer");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING) : "memory");
+        __syncthreads();
+        stamp();
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -271,47 +387,127 @@ dcb_nsplit_kernel(const NsParams p)
                 }
     }
     __syncthreads();            // y1 complete in B; every wave is done with t2 in A
+    stamp();
 
     // ================================================================ ffn.0: t = chunk_add(WSiLU(W0 y1 + b0))   (B -> A)
-    // The wave's C ffn.0 channels in MT passes of 4 tiles: a pass = 128 ffn.0 channels = 32 channels of t
+    // The wave's C ffn.0 channels in MT passes of 4 tiles: a pass = 128 ffn.0 channels = 32 channels of t.
+    // The WSiLU / chunk-sum epilogue of a pass (128 values per lane: 6 VALU operations and one 16-byte table gather
+    // each) runs UNDER THE MFMAs OF THE NEXT PASS, cut into 8 PXT half-tiles of 8 values, each in two stages one
+    // k-slice apart (rows gathered | polynomials + sums): serial, it was 18 % of the kernel (5.5 k of 13.6 k cycles
+    // per pass, profiles/r03_nsplit_ablation.txt). Two accumulator sets alternate; only the last pass's epilogue
+    // is exposed.
+    {
+        constexpr int NHC = 8 * PXT;                      // half-tiles of a pass: (t, np, h, half)
+        constexpr bool PIPE = true;        // (a non-pipelined form, one accumulator set, is kept below for experiments)
+        float16v accs[PIPE ? 2 : 1][4][PXT];
+        float4v crow[8];                                  // (plain vectors: an array of float4 structs went through scratch)
+        float sums[2][4];                                 // [h][g] of the (t, np) pair being finished
+        auto slice_of_hc = [&](int i) { return i * (KS - 1) / NHC; };       // stage A of half-tile i; stage B one slice later
+        // stage A: table rows of the 8 values
+        auto stage_a = [&](const float16v (&a)[4][PXT], int i) {
+            const int t = i / 8, np = (i / 4) % 2, h = (i / 2) % 2, half = i % 2;
 #pragma unroll
-    for (int pass = 0; pass < MT; ++pass) {
-        float16v acc[4][PXT];
-        const int f0 = wave * C + pass * 128;               // first ffn.0 channel of the pass
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb0, f0 + 32 * j);
-        contract(Tag4{}, G::F_DC3 + pass * 4 * KS, bufB, acc);
-#pragma unroll
-        for (int t = 0; t < PXT; ++t)
-#pragma unroll
-            for (int np = 0; np < 2; ++np) {
-                float s[2][4];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float4 c[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) c[e] = wsilu_row_lds<R, true>(acc[2 * np + h][t][e], tab);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float a = acc[2 * np + h][t][4 * g] * wsilu_poly(acc[2 * np + h][t][4 * g], c[4 * g]);
-#pragma unroll
-                        for (int e = 1; e < 4; ++e) a = fmaf(acc[2 * np + h][t][4 * g + e], wsilu_poly(acc[2 * np + h][t][4 * g + e], c[4 * g + e]), a);
-                        s[h][g] = a;
-                    }
-                }
-                // lower half-wave collects the 8 outputs of tile 2 np, upper half-wave those of tile 2 np + 1
-                half8 o;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[0][g]), __float_as_uint(s[1][g]), false, false);
-                    o[2 * g] = to_half(__uint_as_float(sw[0]));
-                    o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
-                }
-                // t channels (f0 + 64 np) / 4 + 8 hi .. + 7
-                *run_ptr(bufA, t, (f0 + 64 * np) / 4) = o;
+            for (int e = 0; e < 8; ++e) {
+                const float4 r = wsilu_row_lds<R, true>(a[2 * np + h][t][8 * half + e], tab);
+                crow[e] = float4v{r.x, r.y, r.z, r.w};
             }
+        };
+        // lower half-wave collects the 8 outputs of tile 2 np, upper half-wave those of tile 2 np + 1
+        auto write_pair = [&](int t, int np, int f0) {
+            half8 o;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sums[0][g]), __float_as_uint(sums[1][g]), false, false);
+                o[2 * g] = to_half(__uint_as_float(sw[0]));
+                o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
+            }
+            *run_ptr(bufA, t, (f0 + 64 * np) / 4) = o;         // t channels (f0 + 64 np) / 4 + 8 hi .. + 7
+        };
+        // stage B: polynomials, chunk sums; behind the last half-tile of a (t, np) pair the 8 outputs go to A
+        auto stage_b = [&](const float16v (&a)[4][PXT], int i, int f0) {
+            const int t = i / 8, np = (i / 4) % 2, h = (i / 2) % 2, half = i % 2;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                auto row = [&](int e) { const float4v r = crow[4 * g + e]; return make_float4(r[0], r[1], r[2], r[3]); };
+                float s = a[2 * np + h][t][8 * half + 4 * g] * wsilu_poly(a[2 * np + h][t][8 * half + 4 * g], row(0));
+#pragma unroll
+                for (int e = 1; e < 4; ++e) {
+                    s = fmaf(a[2 * np + h][t][8 * half + 4 * g + e], wsilu_poly(a[2 * np + h][t][8 * half + 4 * g + e], row(e)), s);
+                }
+                sums[h][2 * half + g] = s;
+            }
+            if (h == 1 && half == 1) write_pair(t, np, f0);
+        };
+        // one piece of the previous pass's epilogue beside the MFMAs of slice ks: arithmetic of half-tile i, THEN the
+        // gathers of half-tile i + 1 into the same 8 row registers (two live row sets - gathers first - pushed the
+        // kernel to all 512 registers and the walk from 11.7 k to 18.3 k cycles per pass)
+        auto epilogue_piece = [&](const float16v (&a)[4][PXT], int f0, int ks) {
+#ifndef NS_EXP_NOEPI
+#pragma unroll
+            for (int i = 0; i < NHC; ++i) {
+                if (slice_of_hc(i) + 1 == ks) stage_b(a, i, f0);
+            }
+#pragma unroll
+            for (int i = 0; i < NHC; ++i) {
+                if (slice_of_hc(i) == ks) stage_a(a, i);
+            }
+#endif
+        };
+        // the whole epilogue of a pass with nothing to hide behind: one accumulator tile at a time, all 16 gathers of
+        // a tile in flight before its polynomials
+        auto epilogue_serial = [&](const float16v (&a)[4][PXT], int f0) {
+#pragma unroll
+            for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                for (int np = 0; np < 2; ++np) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#ifdef NS_EXP_NOEPI
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) sums[h][g] = a[2 * np + h][t][4 * g];
+#else
+                        float4v c[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float4 r = wsilu_row_lds<R, true>(a[2 * np + h][t][e], tab);
+                            c[e] = float4v{r.x, r.y, r.z, r.w};
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            auto row = [&](int e) { const float4v r = c[4 * g + e]; return make_float4(r[0], r[1], r[2], r[3]); };
+                            float s = a[2 * np + h][t][4 * g] * wsilu_poly(a[2 * np + h][t][4 * g], row(0));
+#pragma unroll
+                            for (int e = 1; e < 4; ++e) s = fmaf(a[2 * np + h][t][4 * g + e], wsilu_poly(a[2 * np + h][t][4 * g + e], row(e)), s);
+                            sums[h][g] = s;
+                        }
+#endif
+                    }
+                    write_pair(t, np, f0);
+                }
+        };
+        static_for<0, MT>([&](auto pass_tag) {
+            constexpr int pass = decltype(pass_tag)::value;
+            using F0 = std::integral_constant<int, G::F_DC3 + pass * 4 * KS>;
+            const int f0 = wave * C + pass * 128;               // first ffn.0 channel of the pass
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) bias_tile(accs[PIPE ? (pass & 1) : 0][j][t], lb0, f0 + 32 * j);
+            if constexpr (!PIPE) {
+                // (512 channels x 64 pixels: two accumulator sets do not fit the register file - epilogue behind each pass)
+                contract(Tag4{}, F0{}, bufB, accs[0], no_piece);
+                epilogue_serial(accs[0], f0);
+            } else if constexpr (pass == 0) {
+                contract(Tag4{}, F0{}, bufB, accs[pass & 1], no_piece);
+            } else {
+                contract(Tag4{}, F0{}, bufB, accs[pass & 1],
+                         [&](int ks) { epilogue_piece(accs[(pass - 1) & 1], f0 - 128, ks); });
+            }
+            stamp();
+        });
+        // the last pass's epilogue has nothing to hide behind
+        if (PIPE) epilogue_serial(accs[(MT - 1) & 1], wave * C + (MT - 1) * 128);
+        stamp();
     }
     __syncthreads();            // t complete in A; every wave is done with y1 as an operand
 
@@ -322,7 +518,8 @@ dcb_nsplit_kernel(const NsParams p)
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT + j));
-        contract(TagMT{}, G::F_DC3 + G::F_FFN0, bufA, acc);
+        contract(TagMT{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, bufA, acc, no_piece);
+        stamp();
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -359,27 +556,31 @@ dcb_nsplit_kernel(const NsParams p)
                 }
     }
     __syncthreads();            // y complete in B; every wave is done with t in A
+    stamp();
 
-    // whole rows of an LDS tile -> memory, 16 bytes per lane, consecutive lanes = consecutive chunks of a row
-    auto copy_out = [&](const char* buf, half_t* dst, int ld) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int pos = i * NTHREADS + tid;
-            const int r = pos / CH, lc = pos % CH;
-            const half8 v = *reinterpret_cast<const half8*>(buf + r * PITCH + ((lc ^ (r & 15)) << 4));
-            if (m0 + r < p.M) store_line(dst + static_cast<size_t>(m0 + r) * ld + lc * 8, v);
-        }
-    };
     copy_out(bufB, p.y, p.ldy);
+    stamp();
+    const int next_tile = tile + static_cast<int>(gridDim.x);
+    const bool has_next = next_tile < ntiles;
+    // t2 of the next tile -> A: t (A) is dead, every wave is behind the barrier that follows ffn.2's epilogue
+    if (has_next) dma_tile(p.t2, p.ldt, 0, next_tile * PX);
 
-    // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')   (B -> A)
+    // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')   (B -> B)
     if constexpr (NEXT) {
         float16v acc[MT][PXT];
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, 32 * (wave * MT + j));
-        contract(TagMT{}, G::F_MAIN, bufB, acc);
+        contract(TagMT{}, std::integral_constant<int, G::F_MAIN>{}, bufB, acc, no_piece);
+        // the ring is empty: the first fragments of the next tile go out now and arrive under the epilogue below
+        if (has_next) {
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, RING>([&](auto i) { issue(i); });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp();
+        __syncthreads();        // every wave is done with y as an operand (and with copying it out): B becomes the staging area
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -388,17 +589,36 @@ dcb_nsplit_kernel(const NsParams p)
                 for (int pr = 0; pr < 2; ++pr) {
                     float v[8];
                     runs_of(acc[j][t], pr, v);
-                    float4 c[8];
+                    float4v c[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) c[e] = wsilu_row_lds<R, true>(v[e], tab);
+                    for (int e = 0; e < 8; ++e) {
+                        const float4 r = wsilu_row_lds<R, true>(v[e], tab);
+                        c[e] = float4v{r.x, r.y, r.z, r.w};
+                    }
                     half8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], c[e]));
-                    *run_ptr(bufA, t, 32 * (wave * MT + j) + 16 * pr) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], make_float4(c[e][0], c[e][1], c[e][2], c[e][3])));
+                    *run_ptr(bufB, t, 32 * (wave * MT + j) + 16 * pr) = o;
                 }
         __syncthreads();
-        copy_out(bufA, p.t1n, p.ldt1);
+        stamp();
+        copy_out(bufB, p.t1n, p.ldt1);
+        stamp();
+    } else {
+        if (has_next) {
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, RING>([&](auto i) { issue(i); });
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    if (!has_next) break;
+    // the next tile's t2 has landed (every wave waits for its own pieces, the barrier covers the others'), the rows
+    // copied out of B are read: B is free for the next tile's x
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tile = next_tile;
+    m0 = tile * PX;
+    }       // tiles
 }
 
 // ------------------------------------------------------------------------------------ weight packing
@@ -456,7 +676,15 @@ void launch(const NsParams& p, hipStream_t stream)
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
                   "hipFuncSetAttribute(dcb_nsplit)");
     });
-    const int grid = (p.M + 32 * PXT - 1) / (32 * PXT);
+    // persistent workgroups: one per CU (124 - 160 KB of LDS each), tiles dealt round-robin
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        hip_check(hipGetDevice(&dev), "hipGetDevice");
+        hip_check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
+        return n > 0 ? n : 256;
+    }();
+    const int tiles = (p.M + 32 * PXT - 1) / (32 * PXT);
+    const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;
     const int kflop = (NEXT ? 7 : 6) * C;                 // 2 * pixels * C * kflop = FLOPs of the launch
     if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x40000000, 0.f}, &ev0, &ev1)) {
@@ -467,7 +695,14 @@ void launch(const NsParams& p, hipStream_t stream)
     hip_check(hipGetLastError(), "dcb_nsplit launch");
 }
 
+long long* g_ns_timeline = nullptr;
+
 }  // namespace
+
+void dcb_nsplit_timeline_buffer(long long* device_buffer)
+{
+    g_ns_timeline = device_buffer;
+}
 
 size_t dcb_nsplit_main_halves(int c) { return 4ull * (6 * (c / 128) * (c / 16)) * 512; }
 size_t dcb_nsplit_dc0_halves(int c) { return 4ull * ((c / 128) * (c / 16)) * 512; }
@@ -517,6 +752,7 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     p.b3 = d.b3; p.b0 = d.b0; p.b2 = d.b2; p.b1n = d.b1n; p.q = d.q; p.q2 = d.q2;
     p.wsilu = wsilu_table_device();
     p.y = d.y; p.ldy = d.ldy; p.t1n = d.t1n; p.ldt1 = d.ldt1; p.M = d.pixels; p.shortcut = d.shortcut ? 1 : 0;
+    p.timeline = g_ns_timeline;
     // 64-pixel workgroups when they fill the chip (picture resolution / 8), 32 otherwise (/ 16: 255 workgroups at 1080p)
     const bool wide = d.pixels >= 64 * 200;
     const bool next = d.wnext != nullptr;

@@ -104,6 +104,7 @@ size_t dcb_nsplit_dc0_halves(int c);
 void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, int c, half_t* out, hipStream_t stream);
 void dcb_nsplit_pack_dc0(const half_t* w1, int c, half_t* out, hipStream_t stream);
 void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream);
+void dcb_nsplit_timeline_buffer(long long* device_buffer);    // tuning aid: [workgroups][32] shader-clock stamps
 
 struct ConvKxKDesc {
     const half_t* x = nullptr; int ldx = 0;     // [in_h][in_w][ldx]

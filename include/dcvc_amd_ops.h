@@ -129,6 +129,7 @@ int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H, int W, void* y16,
 int dcvc_gemm_timeline_buffer(void* device_buffer);
 /* the same for dcvc_dcb_core: [workgroups][64] stamps (entry, then one per weight slab) */
 int dcvc_dcb_core_timeline_buffer(void* device_buffer);
+int dcvc_dcb_nsplit_timeline_buffer(void* device_buffer);   /* [workgroups][32] stamps of the N-split block kernel */
 
 /* def_elementwise.h: round_z_cuda / int8_to_dtype_cuda */
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream);

@@ -552,7 +552,8 @@ def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inpla
     (384, 13000, True, False, True, False, False),       # 64-pixel workgroups, ragged; block shortcut + scale after rounding
     (384, 32640, False, True, False, True, True),        # 1080p P8 grid (510 workgroups), fused quant, the chain configuration
     (512, 8160, False, False, False, True, False),       # 1080p P16 grid of the prior networks (255 workgroups of 32 pixels)
-    (512, 777, True, True, True, True, False),
+    (512, 777, True, False, True, True, False),          # shortcut + scale after rounding + next dc.0, ragged
+    (512, 2000, False, True, False, False, True),        # fused quant, in place
     (512, 32640, False, False, False, False, True),      # the hierarchical models' 512-channel blocks at P8
 ])
 def test_dcb_nsplit_equals_launch_sequence(ops, C, P, shortcut, quant, q2, nxt, inplace):

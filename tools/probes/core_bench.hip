@@ -41,6 +41,7 @@ struct Lib {
     conv_fn conv = nullptr;
     dw_fn dw = nullptr;
     tl_fn tl = nullptr;
+    tl_fn ns_tl = nullptr;
     err_fn err = nullptr;
     std::vector<float> us_core, us_core_next, us_seq, us_dw, us_ns, us_ns_next;
 };
@@ -89,6 +90,7 @@ int main(int argc, char** argv)
         l.ns = reinterpret_cast<core_fn>(dlsym(l.h, "dcvc_dcb_nsplit"));
         l.dw = reinterpret_cast<dw_fn>(dlsym(l.h, "dcvc_dwconv3x3"));
         l.tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_core_timeline_buffer"));
+        l.ns_tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_nsplit_timeline_buffer"));
         l.err = reinterpret_cast<err_fn>(dlsym(l.h, "dcvc_last_error"));
         if (!l.core || !l.conv || !l.err) { fprintf(stderr, "%s: missing symbols\n", l.path.c_str()); return 1; }
     }
@@ -169,6 +171,7 @@ int main(int argc, char** argv)
         if (l.ns) {
             OK(hipMemset(y, 0, hy.size() * 2));
             OK(hipMemset(t1, 0, hy.size() * 2));
+            OK(hipDeviceSynchronize());        // the memsets run on the null stream, which `st` (non-blocking) does not wait for
             nsplit(l, true);
             OK(hipStreamSynchronize(st));
             OK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost));
@@ -182,11 +185,41 @@ int main(int argc, char** argv)
                    bn, flop * 6 / 7 / bn / 1e6, static_cast<unsigned long long>(s2), static_cast<unsigned long long>(s3),
                    (s2 == sum && s3 == sum1) ? "(= dcb_core)" : "(DIFFERS from dcb_core)");
         }
+        if (l.ns && l.ns_tl) {
+            long long* tl = nullptr;
+            const size_t rows = 2048;
+            OK(hipMalloc(&tl, rows * 32 * 8));
+            OK(hipMemset(tl, 0, rows * 32 * 8));
+            OK(hipDeviceSynchronize());
+            chk(l, l.ns_tl(tl), "timeline");
+            nsplit(l, true);
+            OK(hipStreamSynchronize(st));
+            chk(l, l.ns_tl(nullptr), "timeline");
+            std::vector<long long> h(rows * 32);
+            OK(hipMemcpy(h.data(), tl, rows * 32 * 8, hipMemcpyDeviceToHost));
+            OK(hipFree(tl));
+            static const char* names[13] = {"prologue", "dc.3 mfma", "x + dc.3 epi + bar", "ffn0.0 mfma", "ffn0.1 mfma | epi 0", "ffn0.2 mfma | epi 1", "epi 2",
+                                             "bar + ffn.2 mfma", "epi + bar", "y out", "dc.0 mfma", "epi + bar", "t1n out"};
+            printf("  nsplit timeline (median cycles over workgroups):");
+            for (int i = 0; i < 13; ++i) {
+                std::vector<float> d;
+                for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && h[w * 32 + i + 1] != 0) d.push_back(static_cast<float>(h[w * 32 + i + 1] - h[w * 32 + i]));
+                printf(" %s %.0f |", names[i], median(d));
+            }
+            std::vector<float> tot, start;
+            long long t0 = 0;
+            for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && (t0 == 0 || h[w * 32] < t0)) t0 = h[w * 32];
+            for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0) { tot.push_back(static_cast<float>(h[w * 32 + 13] - h[w * 32])); start.push_back(static_cast<float>(h[w * 32] - t0)); }
+            std::sort(start.begin(), start.end());
+            printf(" total %.0f | workgroups %zu, start of the median / last workgroup %.0f / %.0f\n", median(tot), tot.size(),
+                   start.empty() ? 0.f : start[start.size() / 2], start.empty() ? 0.f : start.back());
+        }
         if (l.tl) {
             long long* tl = nullptr;
             const size_t rows = 1024;
             OK(hipMalloc(&tl, rows * 64 * 8));
             OK(hipMemset(tl, 0, rows * 64 * 8));
+            OK(hipDeviceSynchronize());
             chk(l, l.tl(tl), "timeline");
             core(l, true);
             OK(hipStreamSynchronize(st));
