@@ -421,10 +421,25 @@ def roofline(work, n=len(QPS)):
     # in, the block output and the next block's dc.0 output out ([P8][384] fp16 each) + 2.06 MB of weights
     P8 = ((work.height + 15) // 16 * 2) * ((work.width + 15) // 16 * 2)
     core_bytes = 4 * P8 * 384 * 2 + 7 * 384 * 384 * 2
-    kernels = [k for k in (part(family == f, name, core_bytes if f in (1, 4) else None) for f, name in KERNEL_NAMES.items()) if k]
+    kernels = []
+    for f, name in KERNEL_NAMES.items():
+        sel = family == f
+        if f == 4:
+            # one entry per template instantiation of the N-split block kernel: <C, pixels per workgroup> follows from (N, M)
+            for (m, c) in sorted({(int(a), int(b)) for a, b in zip(buf["M"][sel], buf["N"][sel])}):
+                one = sel & (buf["M"] == m) & (buf["N"] == c)
+                wide = m >= 64 * 200
+                k = part(one, "%s<%d, %d px>" % (name, c, 64 if wide else 32), (4 * m * c * 2 + 7 * c * c * 2) if c == 384 else None)
+                if k:
+                    k["pixels"] = m
+                    kernels.append(k)
+            continue
+        k = part(sel, name, core_bytes if f == 1 else None)
+        if k:
+            kernels.append(k)
     total_ms, total_fl = float(buf["ms"].sum()), float(flops.sum())
     dom = max(kernels, key=lambda k: k["ms_per_step"])
-    traffic, source = pmc_traffic(dom["kernel"])
+    traffic, source = pmc_traffic(dom["kernel"].split("<")[0])
     return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": dom["frac"], "traffic": traffic, "traffic_source": source,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
@@ -513,7 +528,7 @@ def main():
     # the same loop for >= --min-seconds: the K-step region of a short driver run lasts a fraction of a second
     sustained = None
     if args.min_seconds > 0:
-        more = max(args.steps, int(np.ceil(args.min_seconds * args.steps / max(elapsed, 1e-6))))
+        more = max(args.steps, int(np.ceil(1.15 * args.min_seconds * args.steps / max(elapsed, 1e-6))))      # (a margin: warm steps run faster)
         more = min(more, 100 * args.steps)
         sync()
         t0 = time.perf_counter()

@@ -142,15 +142,15 @@ namespace {
 // dcvc_dcb_nsplit takes the weights as the reference lays them out; the kernel wants its per-wave fragment streams.
 // Packed copies are cached per weight pointer (the codecs pack once at set_param time, dcvc::DcbW::load; this
 // cache serves the operator-level entry point: tests and tools). Bounded: the oldest entries are dropped.
-struct PackedEntry { const void* a; const void* b; const void* c; int width; void* packed; };
+struct PackedEntry { const void* a; const void* b; const void* c; int width, inner; void* packed; };
 std::vector<PackedEntry> g_packed;
 std::mutex g_packed_mu;
 
-const dcvc::half_t* packed_for(const void* a, const void* b, const void* c, int width, bool dc0, hipStream_t st)
+const dcvc::half_t* packed_for(const void* a, const void* b, const void* c, int width, int inner, bool dc0, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_packed_mu);
     for (const PackedEntry& e : g_packed) {
-        if (e.a == a && e.b == b && e.c == c && e.width == width) return static_cast<const dcvc::half_t*>(e.packed);
+        if (e.a == a && e.b == b && e.c == c && e.width == width && e.inner == inner) return static_cast<const dcvc::half_t*>(e.packed);
     }
     if (g_packed.size() >= 64) {
         (void)hipDeviceSynchronize();
@@ -158,11 +158,11 @@ const dcvc::half_t* packed_for(const void* a, const void* b, const void* c, int 
         g_packed.erase(g_packed.begin());
     }
     void* out = nullptr;
-    const size_t halves = dc0 ? dcvc::dcb_nsplit_dc0_halves(width) : dcvc::dcb_nsplit_main_halves(width);
+    const size_t halves = dc0 ? dcvc::dcb_nsplit_dc0_halves(width, inner) : dcvc::dcb_nsplit_main_halves(width, inner);
     dcvc::hip_check(hipMalloc(&out, halves * 2), "hipMalloc(packed weights)");
-    if (dc0) dcvc::dcb_nsplit_pack_dc0(H(a), width, static_cast<dcvc::half_t*>(out), st);
-    else dcvc::dcb_nsplit_pack_main(H(a), H(b), H(c), width, static_cast<dcvc::half_t*>(out), st);
-    g_packed.push_back(PackedEntry{a, b, c, width, out});
+    if (dc0) dcvc::dcb_nsplit_pack_dc0(H(a), width, inner, static_cast<dcvc::half_t*>(out), st);
+    else dcvc::dcb_nsplit_pack_main(H(a), H(b), H(c), width, inner, static_cast<dcvc::half_t*>(out), st);
+    g_packed.push_back(PackedEntry{a, b, c, width, inner, out});
     return static_cast<const dcvc::half_t*>(out);
 }
 }  // namespace
@@ -170,19 +170,21 @@ const dcvc::half_t* packed_for(const void* a, const void* b, const void* c, int 
 int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
                     const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
                     const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
-                    int pixels, int c, int shortcut, void* stream)
+                    int pixels, int c, int ci, int shortcut, void* stream)
 {
     return dcvc::guarded([&] {
         dcvc::kernels_init();
-        if (c != 384 && c != 512) throw std::invalid_argument("dcb_nsplit: block width must be 384 or 512");
+        if (!dcvc::dcb_nsplit_shape(c, ci)) {
+            throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (384, 384), (512, 512), (512, 256) or (256, 128)");
+        }
         if (!w3 || !w0 || !w2) throw std::invalid_argument("dcb_nsplit: missing operand");
         dcvc::DcbNsplitDesc d;
         d.t2 = H(t2); d.ldt = ldt; d.x = H(x); d.ldx = ldx;
-        d.wmain = packed_for(w3, w0, w2, c, false, S(stream));
-        d.wnext = w1n != nullptr ? packed_for(w1n, nullptr, nullptr, c, true, S(stream)) : nullptr;
+        d.wmain = packed_for(w3, w0, w2, c, ci, false, S(stream));
+        d.wnext = w1n != nullptr ? packed_for(w1n, nullptr, nullptr, c, ci, true, S(stream)) : nullptr;
         d.b3 = H(b3); d.b0 = H(b0); d.b2 = H(b2); d.b1n = H(b1n); d.q = H(q); d.q2 = H(q2);
         d.t1n = H(t1n); d.ldt1 = ldt1; d.y = H(y); d.ldy = ldy;
-        d.pixels = pixels; d.c = c; d.shortcut = shortcut != 0;
+        d.pixels = pixels; d.c = c; d.ci = ci; d.shortcut = shortcut != 0;
         dcvc::dcb_nsplit(d, S(stream));
     });
 }

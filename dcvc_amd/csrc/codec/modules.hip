@@ -161,10 +161,10 @@ void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
     }
     if (dcb_nsplit_supported(c, cdc, cffn) && dc0.b && dc3.b && ffn0.b && ffn2.b) {
         // kernels/dcb_nsplit.hip: per-wave linear streams of MFMA weight fragments, packed once on the device
-        packed_main = mem.alloc_half(dcb_nsplit_main_halves(c));
-        packed_dc0 = mem.alloc_half(dcb_nsplit_dc0_halves(c));
-        dcb_nsplit_pack_main(dc3.w, ffn0.w, ffn2.w, c, packed_main, nullptr);
-        dcb_nsplit_pack_dc0(dc0.w, c, packed_dc0, nullptr);
+        packed_main = mem.alloc_half(dcb_nsplit_main_halves(c, cdc));
+        packed_dc0 = mem.alloc_half(dcb_nsplit_dc0_halves(c, cdc));
+        dcb_nsplit_pack_main(dc3.w, ffn0.w, ffn2.w, c, cdc, packed_main, nullptr);
+        dcb_nsplit_pack_dc0(dc0.w, c, cdc, packed_dc0, nullptr);
         hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(pack)");
     }
 }
@@ -176,7 +176,7 @@ bool DcbW::core_fused() const
 
 bool DcbW::feeds(const DcbW& next) const
 {
-    return core_fused() && next.core_fused() && !next.has_adaptor && next.c == c && nsplit() == next.nsplit();
+    return core_fused() && next.core_fused() && !next.has_adaptor && next.c == c && next.cdc == cdc && nsplit() == next.nsplit();
 }
 
 void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut,
@@ -204,7 +204,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
     } else if (shortcut && x.p == y.p) {
         throw std::invalid_argument("DepthConvBlock with shortcut cannot run in place");
     }
-    const bool tail = dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr &&
+    const bool tail = !nsplit() && dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr &&
                       dc3.b != nullptr && dc0.b != nullptr;
     const bool tail_dc0 = tail && dcb_tail_takes_dc0() && in.p != y.p;      // reads neighbours' input: not in place
     if (!tail_dc0 && !dc0_done) {   // dc.0 + WSiLU
@@ -230,7 +230,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         DcbNsplitDesc d;
         d.t2 = s.t2; d.ldt = cdc; d.x = in.p; d.ldx = in.ld;
         d.wmain = packed_main; d.b3 = dc3.b; d.b0 = ffn0.b; d.b2 = ffn2.b;
-        d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.shortcut = shortcut;
+        d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.ci = cdc; d.shortcut = shortcut;
         if (next != nullptr) {
             d.wnext = next->packed_dc0; d.b1n = next->dc0.b; d.t1n = s.t1; d.ldt1 = next->cdc;
         }

@@ -84,25 +84,27 @@ void dcb_core(const DcbCoreDesc& d, hipStream_t stream);
 
 // The same block in "N-split" form (dcb_nsplit.hip, round 3): activations in LDS, every wave owns a quarter of
 // the output channels and streams ITS weight fragments straight from L2 out of a pre-packed per-wave stream
-// (dcb_nsplit_pack_main / _dc0, packed once at set_param time). c in {384, 512}. Bit-identical to dcb_core and to
+// (dcb_nsplit_pack_main / _dc0, packed once at set_param time). (c, ci) = (block width, inner width cdc = cffn):
+// (384, 384), (512, 512), and the half-width `dcb2` blocks (512, 256), (256, 128). Bit-identical to dcb_core and to
 // the launch sequence. y may alias x (a workgroup reads and writes only its own pixels).
 struct DcbNsplitDesc {
     const half_t* t2 = nullptr; int ldt = 0;
     const half_t* x = nullptr; int ldx = 0;
-    const half_t* wmain = nullptr;              // packed dc.3 | ffn.0 | ffn.2 (dcb_nsplit_main_halves(c) halves)
-    const half_t* wnext = nullptr;              // packed dc.0 of the NEXT block (dcb_nsplit_dc0_halves(c)) or null
+    const half_t* wmain = nullptr;              // packed dc.3 | ffn.0 | ffn.2 (dcb_nsplit_main_halves(c, ci) halves)
+    const half_t* wnext = nullptr;              // packed dc.0 of the NEXT block (dcb_nsplit_dc0_halves(c, ci)) or null
     const half_t* b3 = nullptr; const half_t* b0 = nullptr; const half_t* b2 = nullptr; const half_t* b1n = nullptr;
     const half_t* q = nullptr; const half_t* q2 = nullptr;
     half_t* t1n = nullptr; int ldt1 = 0;
     half_t* y = nullptr; int ldy = 0;
-    int pixels = 0, c = 0;
+    int pixels = 0, c = 0, ci = 0;
     bool shortcut = false;
 };
-bool dcb_nsplit_supported(int c, int cdc, int cffn);          // DCVC_NSPLIT=0 switches it off (A/B)
-size_t dcb_nsplit_main_halves(int c);
-size_t dcb_nsplit_dc0_halves(int c);
-void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, int c, half_t* out, hipStream_t stream);
-void dcb_nsplit_pack_dc0(const half_t* w1, int c, half_t* out, hipStream_t stream);
+bool dcb_nsplit_shape(int c, int ci);                         // a shape the kernel is instantiated for
+bool dcb_nsplit_supported(int c, int cdc, int cffn);          // DCVC_NSPLIT: 0 = off, 1 = full-width blocks only (A/B)
+size_t dcb_nsplit_main_halves(int c, int ci);
+size_t dcb_nsplit_dc0_halves(int c, int ci);
+void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, int c, int ci, half_t* out, hipStream_t stream);
+void dcb_nsplit_pack_dc0(const half_t* w1, int c, int ci, half_t* out, hipStream_t stream);
 void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream);
 void dcb_nsplit_timeline_buffer(long long* device_buffer);    // tuning aid: [workgroups][32] shader-clock stamps
 

@@ -82,14 +82,16 @@ int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w
                   const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
                   int pixels, int c, int shortcut, void* stream);
 
-/* The same operator, same arguments, through the N-split kernel (round 3: activations in LDS, every wave owns a quarter
+/* The same operator (plus the inner width ci = cdc = cffn) through the N-split kernel (round 3: activations in LDS, every wave owns a quarter
  * of the output channels and streams its weight fragments from a packed copy of w3 | w0 | w2 [| w1n] that this entry point
- * builds on first use and caches per weight pointer - the codecs pack once at set_param time). c in {384, 512}.
- * Bit-identical to dcvc_dcb_core and to the separate launches. */
+ * builds on first use and caches per weight pointer - the codecs pack once at set_param time).
+ * (c, ci) in {(384, 384), (512, 512)} - the full-width blocks dcvc_dcb_core serves - and {(512, 256), (256, 128)}: the
+ * half-width `dcb2` blocks of the inter models (layers.py:128-159; w3 [c][ci], w0 [4 ci][c], w2 [c][ci], w1n [ci][c]).
+ * Bit-identical to dcvc_dcb_core / dcvc_dcb_tail and to the separate launches. */
 int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
                     const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
                     const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
-                    int pixels, int c, int shortcut, void* stream);
+                    int pixels, int c, int ci, int shortcut, void* stream);
 
 /* DepthConvBlockProxy::forward behind dc.0 (layers_proxy.cpp:79-98: d3x3, conv1x1_bias_shortcut,
  * conv1x1_bias_wsilu_chunk_add, conv1x1_bias_shortcut[2][_with_quant]) in one launch for the

@@ -45,7 +45,7 @@ class Ops:
         self.dcb_core = _f("dcvc_dcb_core", [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci,
                                              ci, ci, ci, vp])
         self.dcb_nsplit = _f("dcvc_dcb_nsplit", [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci,
-                                                 ci, ci, ci, vp])
+                                                 ci, ci, ci, ci, vp])
         self.scale_clamped = _f("dcvc_scale_clamped", [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp])
 
 

@@ -546,62 +546,69 @@ def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inpla
         assert (t1 == 7.0).all()
 
 
-@pytest.mark.parametrize("C,P,shortcut,quant,q2,nxt,inplace", [
-    (384, 64, False, False, False, False, False),        # one 64-pixel workgroup
-    (384, 100, False, False, False, True, True),         # 32-pixel workgroups, ragged last one, in place, next dc.0
-    (384, 13000, True, False, True, False, False),       # 64-pixel workgroups, ragged; block shortcut + scale after rounding
-    (384, 32640, False, True, False, True, True),        # 1080p P8 grid (510 workgroups), fused quant, the chain configuration
-    (512, 8160, False, False, False, True, False),       # 1080p P16 grid of the prior networks (255 workgroups of 32 pixels)
-    (512, 777, True, False, True, True, False),          # shortcut + scale after rounding + next dc.0, ragged
-    (512, 2000, False, True, False, False, True),        # fused quant, in place
-    (512, 32640, False, False, False, False, True),      # the hierarchical models' 512-channel blocks at P8
+@pytest.mark.parametrize("C,CI,P,shortcut,quant,q2,nxt,inplace", [
+    (384, 384, 64, False, False, False, False, False),   # one 64-pixel workgroup
+    (384, 384, 100, False, False, False, True, True),    # 32-pixel workgroups, ragged last one, in place, next dc.0
+    (384, 384, 13000, True, False, True, False, False),  # 64-pixel workgroups, ragged; block shortcut + scale after rounding
+    (384, 384, 32640, False, True, False, True, True),   # 1080p P8 grid (510 tiles), fused quant, the chain configuration
+    (512, 512, 8160, False, False, False, True, False),  # 1080p P16 grid of the prior networks (255 workgroups of 32 pixels)
+    (512, 512, 777, True, False, True, True, False),     # shortcut + scale after rounding + next dc.0, ragged
+    (512, 512, 2000, False, True, False, False, True),   # fused quant, in place
+    (512, 512, 32640, False, False, False, False, True), # 512-channel full-width blocks at P8
+    (512, 256, 32640, False, False, False, True, True),  # the hierarchical models' dcb2 chains at P8 (layers.py:128-159)
+    (512, 256, 777, True, False, True, True, False),     # ... 32-pixel workgroups, ragged, both residuals
+    (512, 256, 13000, False, True, False, False, False), # ... fused quant, ragged 64-pixel workgroups
+    (256, 128, 32640, False, False, False, True, True),  # the low-delay model's dcb2 chains at P8
+    (256, 128, 100, True, False, True, False, False),    # ... 32-pixel workgroups (the WSiLU table behind LDS padding)
+    (256, 128, 20000, False, True, False, True, False),  # ... ragged, fused quant, next dc.0
 ])
-def test_dcb_nsplit_equals_launch_sequence(ops, C, P, shortcut, quant, q2, nxt, inplace):
+def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, nxt, inplace):
     """The same block through kernels/dcb_nsplit.hip (round 3: activations in LDS, every wave streams its quarter of
     every weight matrix from a packed copy) == the launch sequence conv1x1(dc.3, residual) -> conv1x1(ffn.0, wsilu,
-    chunk_add) -> conv1x1(ffn.2, residuals, quant) (-> conv1x1(dc.0, wsilu)), bit for bit, for both block widths, both
-    workgroup sizes, ragged grids, in place and out of place; where dcb_core exists (C = 384) it agrees too."""
+    chunk_add) -> conv1x1(ffn.2, residuals, quant) (-> conv1x1(dc.0, wsilu)), bit for bit, for full- and half-width
+    blocks (CI = inner width), both workgroup sizes, ragged grids, in place and out of place; where dcb_core exists
+    (C = 384) it agrees too."""
     from gpu_util import call, ptr, stream
     dev = "cuda"
     ldx = C + 64
     xbuf = _rand((P, ldx), 1.0, 401).to(dev)
-    t2 = _rand((P, C), 1.0, 402).to(dev)
-    w3 = (_rand((C, C), 1.0, 403) / C ** 0.5).half().to(dev)
+    t2 = _rand((P, CI), 1.0, 402).to(dev)
+    w3 = (_rand((C, CI), 1.0, 403) / CI ** 0.5).half().to(dev)
     b3 = _rand((C,), 0.3, 404).to(dev)
-    w0 = (_rand((4 * C, C), 1.0, 405) / C ** 0.5).half().to(dev)
-    b0 = _rand((4 * C,), 0.3, 406).to(dev)
-    w2 = (_rand((C, C), 1.0, 407) / C ** 0.5).half().to(dev)
+    w0 = (_rand((4 * CI, C), 1.0, 405) / C ** 0.5).half().to(dev)
+    b0 = _rand((4 * CI,), 0.3, 406).to(dev)
+    w2 = (_rand((C, CI), 1.0, 407) / CI ** 0.5).half().to(dev)
     b2 = _rand((C,), 0.3, 408).to(dev)
-    w1 = (_rand((C, C), 1.0, 409) / C ** 0.5).half().to(dev)
-    b1 = _rand((C,), 0.3, 410).to(dev)
+    w1 = (_rand((CI, C), 1.0, 409) / C ** 0.5).half().to(dev)
+    b1 = _rand((CI,), 0.3, 410).to(dev)
     q = (_rand((C,), 0.2, 411) + 1.0).half().to(dev) if quant else None
     qq = (_rand((C,), 0.2, 412) + 1.0).half().to(dev) if q2 else None
     y1 = torch.zeros((P, C), dtype=torch.half, device=dev)
-    t = torch.zeros((P, C), dtype=torch.half, device=dev)
+    t = torch.zeros((P, CI), dtype=torch.half, device=dev)
     want = torch.zeros((P, C), dtype=torch.half, device=dev)
-    want_t1 = torch.zeros((P, C), dtype=torch.half, device=dev)
-    call(ops.conv1x1, ptr(t2), C, ptr(w3), ptr(b3), ptr(xbuf), ldx, None, 0, None, None, ptr(y1), C, P, C, C, 0, stream())
-    call(ops.conv1x1, ptr(y1), C, ptr(w0), ptr(b0), None, 0, None, 0, None, None, ptr(t), C, P, C, 4 * C, 3, stream())
-    call(ops.conv1x1, ptr(t), C, ptr(w2), ptr(b2), ptr(y1), C, ptr(xbuf) if shortcut else None, ldx, ptr(q), ptr(qq),
-         ptr(want), C, P, C, C, 0, stream())
-    call(ops.conv1x1, ptr(want), C, ptr(w1), ptr(b1), None, 0, None, 0, None, None, ptr(want_t1), C, P, C, C, 1, stream())
+    want_t1 = torch.zeros((P, CI), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(t2), CI, ptr(w3), ptr(b3), ptr(xbuf), ldx, None, 0, None, None, ptr(y1), C, P, CI, C, 0, stream())
+    call(ops.conv1x1, ptr(y1), C, ptr(w0), ptr(b0), None, 0, None, 0, None, None, ptr(t), CI, P, C, 4 * CI, 3, stream())
+    call(ops.conv1x1, ptr(t), CI, ptr(w2), ptr(b2), ptr(y1), C, ptr(xbuf) if shortcut else None, ldx, ptr(q), ptr(qq),
+         ptr(want), C, P, CI, C, 0, stream())
+    call(ops.conv1x1, ptr(want), C, ptr(w1), ptr(b1), None, 0, None, 0, None, None, ptr(want_t1), CI, P, C, CI, 1, stream())
     torch.cuda.synchronize()
 
-    def run(op):
+    def run(op, *inner):
         if inplace:
             ybuf, ldy = xbuf.clone(), ldx
             xin = ybuf
         else:
             ybuf, ldy = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev), C + 8
             xin = xbuf
-        t1 = torch.full((P, C + 8), 7.0, dtype=torch.half, device=dev)
-        call(op, ptr(t2), C, ptr(xin), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), ptr(qq),
-             ptr(w1) if nxt else None, ptr(b1) if nxt else None, ptr(t1) if nxt else None, C + 8, ptr(ybuf), ldy,
-             P, C, 1 if shortcut else 0, stream())
+        t1 = torch.full((P, CI + 8), 7.0, dtype=torch.half, device=dev)
+        call(op, ptr(t2), CI, ptr(xin), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), ptr(qq),
+             ptr(w1) if nxt else None, ptr(b1) if nxt else None, ptr(t1) if nxt else None, CI + 8, ptr(ybuf), ldy,
+             P, C, *inner, 1 if shortcut else 0, stream())
         torch.cuda.synchronize()
         return ybuf, t1
 
-    ybuf, t1 = run(ops.dcb_nsplit)
+    ybuf, t1 = run(ops.dcb_nsplit, CI)
     bad = int((ybuf[:, :C] != want).sum())
     assert bad == 0, "y: %d of %d outputs differ" % (bad, want.numel())
     if inplace:
@@ -609,9 +616,9 @@ def test_dcb_nsplit_equals_launch_sequence(ops, C, P, shortcut, quant, q2, nxt, 
     else:
         assert (ybuf[:, C:] == 9.0).all()
     if nxt:
-        bad = int((t1[:, :C] != want_t1).sum())
+        bad = int((t1[:, :CI] != want_t1).sum())
         assert bad == 0, "next dc.0: %d of %d outputs differ" % (bad, want_t1.numel())
-        assert (t1[:, C:] == 7.0).all()
+        assert (t1[:, CI:] == 7.0).all()
     else:
         assert (t1 == 7.0).all()
     if C == 384:

@@ -27,6 +27,8 @@
 
 typedef int (*core_fn)(const void*, int, const void*, int, const void*, const void*, const void*, const void*, const void*,
                        const void*, const void*, const void*, const void*, const void*, void*, int, void*, int, int, int, int, void*);
+typedef int (*ns_fn)(const void*, int, const void*, int, const void*, const void*, const void*, const void*, const void*,
+                     const void*, const void*, const void*, const void*, const void*, void*, int, void*, int, int, int, int, int, void*);
 typedef int (*conv_fn)(const void*, int, const void*, const void*, const void*, int, const void*, int, const void*, const void*,
                        void*, int, int, int, int, int, void*);
 typedef int (*dw_fn)(const void*, int, const void*, void*, int, int, int, int, void*);
@@ -37,7 +39,7 @@ struct Lib {
     std::string path;
     void* h = nullptr;
     core_fn core = nullptr;
-    core_fn ns = nullptr;          // dcvc_dcb_nsplit (same signature), round 3
+    ns_fn ns = nullptr;            // dcvc_dcb_nsplit (+ the inner width), round 3
     conv_fn conv = nullptr;
     dw_fn dw = nullptr;
     tl_fn tl = nullptr;
@@ -73,41 +75,45 @@ static float median(std::vector<float> v)
 
 int main(int argc, char** argv)
 {
-    int P = 32640, rounds = 5, n = 20, H = 136, W = 240;
+    int P = 32640, rounds = 5, n = 20, H = 136, W = 240, C = 384, CI = 0;
     std::vector<Lib> libs;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-p") && i + 1 < argc) { P = atoi(argv[++i]); H = 1; W = P; }
         else if (!strcmp(argv[i], "-r") && i + 1 < argc) rounds = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-n") && i + 1 < argc) n = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-c") && i + 1 < argc) C = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-i") && i + 1 < argc) CI = atoi(argv[++i]);
         else { Lib l; l.path = argv[i]; libs.push_back(l); }
     }
-    if (libs.empty()) { fprintf(stderr, "usage: core_bench [-p pixels] [-r rounds] [-n launches] lib.so ...\n"); return 2; }
+    if (CI == 0) CI = C;
+    const bool has_core = C == 384 && CI == 384;
+    if (libs.empty()) { fprintf(stderr, "usage: core_bench [-p pixels] [-r rounds] [-n launches] [-c block width] [-i inner width] lib.so ...\n"); return 2; }
     for (auto& l : libs) {
         l.h = dlopen(l.path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", l.path.c_str(), dlerror()); return 1; }
         l.core = reinterpret_cast<core_fn>(dlsym(l.h, "dcvc_dcb_core"));
         l.conv = reinterpret_cast<conv_fn>(dlsym(l.h, "dcvc_conv1x1"));
-        l.ns = reinterpret_cast<core_fn>(dlsym(l.h, "dcvc_dcb_nsplit"));
+        l.ns = reinterpret_cast<ns_fn>(dlsym(l.h, "dcvc_dcb_nsplit"));
         l.dw = reinterpret_cast<dw_fn>(dlsym(l.h, "dcvc_dwconv3x3"));
         l.tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_core_timeline_buffer"));
         l.ns_tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_nsplit_timeline_buffer"));
         l.err = reinterpret_cast<err_fn>(dlsym(l.h, "dcvc_last_error"));
         if (!l.core || !l.conv || !l.err) { fprintf(stderr, "%s: missing symbols\n", l.path.c_str()); return 1; }
     }
-    const int C = 384;
     std::mt19937 rng(1234);
     const float ws = 1.7f / sqrtf(static_cast<float>(C));       // keeps activations O(1) through the block
     void* x = device_random(static_cast<size_t>(P) * C, 1.0f, rng);
-    void* t2 = device_random(static_cast<size_t>(P) * C, 1.0f, rng);
-    void* w3 = device_random(static_cast<size_t>(C) * C, ws, rng);
-    void* w2 = device_random(static_cast<size_t>(C) * C, ws, rng);
-    void* w1 = device_random(static_cast<size_t>(C) * C, ws, rng);
-    void* w0 = device_random(static_cast<size_t>(4) * C * C, ws, rng);
-    void* wd = device_random(static_cast<size_t>(9) * C, 0.3f, rng);
+    const float wsi = 1.7f / sqrtf(static_cast<float>(CI));
+    void* t2 = device_random(static_cast<size_t>(P) * CI, 1.0f, rng);
+    void* w3 = device_random(static_cast<size_t>(C) * CI, wsi, rng);
+    void* w2 = device_random(static_cast<size_t>(C) * CI, wsi, rng);
+    void* w1 = device_random(static_cast<size_t>(CI) * C, ws, rng);
+    void* w0 = device_random(static_cast<size_t>(4) * CI * C, ws, rng);
+    void* wd = device_random(static_cast<size_t>(9) * CI, 0.3f, rng);
     void* b3 = device_random(C, 0.5f, rng);
     void* b2 = device_random(C, 0.5f, rng);
-    void* b1 = device_random(C, 0.5f, rng);
-    void* b0 = device_random(4 * C, 0.5f, rng);
+    void* b1 = device_random(CI, 0.5f, rng);
+    void* b0 = device_random(4 * CI, 0.5f, rng);
     void *y, *t1, *y1, *t;
     for (void** p : {&y, &t1, &y1, &t}) { OK(hipMalloc(p, static_cast<size_t>(P) * C * 2)); OK(hipMemset(*p, 0, static_cast<size_t>(P) * C * 2)); }
     hipStream_t st;
@@ -121,14 +127,14 @@ int main(int argc, char** argv)
                       y, C, P, C, 0, st), "dcb_core");
     };
     auto nsplit = [&](Lib& l, bool next) {
-        chk(l, l.ns(t2, C, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, next ? w1 : nullptr, next ? b1 : nullptr, next ? t1 : nullptr, C,
-                    y, C, P, C, 0, st), "dcb_nsplit");
+        chk(l, l.ns(t2, CI, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, next ? w1 : nullptr, next ? b1 : nullptr, next ? t1 : nullptr, CI,
+                    y, C, P, C, CI, 0, st), "dcb_nsplit");
     };
     auto seq = [&](Lib& l) {
-        chk(l, l.conv(t2, C, w3, b3, x, C, nullptr, 0, nullptr, nullptr, y1, C, P, C, C, 0, st), "conv");
-        chk(l, l.conv(y1, C, w0, b0, nullptr, 0, nullptr, 0, nullptr, nullptr, t, C, P, C, 4 * C, 3, st), "conv");
-        chk(l, l.conv(t, C, w2, b2, y1, C, nullptr, 0, nullptr, nullptr, y, C, P, C, C, 0, st), "conv");
-        chk(l, l.conv(y, C, w1, b1, nullptr, 0, nullptr, 0, nullptr, nullptr, t1, C, P, C, C, 1, st), "conv");
+        chk(l, l.conv(t2, CI, w3, b3, x, C, nullptr, 0, nullptr, nullptr, y1, C, P, CI, C, 0, st), "conv");
+        chk(l, l.conv(y1, C, w0, b0, nullptr, 0, nullptr, 0, nullptr, nullptr, t, CI, P, C, 4 * CI, 3, st), "conv");
+        chk(l, l.conv(t, CI, w2, b2, y1, C, nullptr, 0, nullptr, nullptr, y, C, P, CI, C, 0, st), "conv");
+        chk(l, l.conv(y, C, w1, b1, nullptr, 0, nullptr, 0, nullptr, nullptr, t1, CI, P, C, CI, 1, st), "conv");
     };
     auto timed = [&](auto&& fn) {
         for (int i = 0; i < 3; ++i) fn();
@@ -143,20 +149,22 @@ int main(int argc, char** argv)
     };
     for (int r = 0; r < rounds; ++r) {
         for (auto& l : libs) {
-            l.us_core_next.push_back(timed([&] { core(l, true); }));
-            l.us_core.push_back(timed([&] { core(l, false); }));
+            if (has_core) {
+                l.us_core_next.push_back(timed([&] { core(l, true); }));
+                l.us_core.push_back(timed([&] { core(l, false); }));
+            }
             l.us_seq.push_back(timed([&] { seq(l); }));
             if (l.ns) {
                 l.us_ns_next.push_back(timed([&] { nsplit(l, true); }));
                 l.us_ns.push_back(timed([&] { nsplit(l, false); }));
             }
-            if (l.dw && H > 1) l.us_dw.push_back(timed([&] { chk(l, l.dw(x, C, wd, t, C, H, W, C, st), "dwconv"); }));
+            if (l.dw && H > 1) l.us_dw.push_back(timed([&] { chk(l, l.dw(t2, CI, wd, t, CI, H, W, CI, st), "dwconv"); }));
         }
     }
-    const double flop = 2.0 * P * 7 * C * C;
+    const double flop = 2.0 * P * 7 * C * CI;
     std::vector<uint16_t> hy(static_cast<size_t>(P) * C);
     for (auto& l : libs) {
-        core(l, true);
+        if (has_core) core(l, true); else seq(l);      // the reference result: dcb_core where it exists, else the four launches
         OK(hipStreamSynchronize(st));
         OK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost));
         uint64_t sum = 0;
@@ -183,7 +191,7 @@ int main(int argc, char** argv)
             const float an = median(l.us_ns_next), bn = median(l.us_ns);
             printf("  dcb_nsplit + next dc.0 %7.1f us %6.0f TFLOP/s | dcb_nsplit %7.1f us %6.0f TFLOP/s | y %016llx t1 %016llx %s\n", an, flop / an / 1e6,
                    bn, flop * 6 / 7 / bn / 1e6, static_cast<unsigned long long>(s2), static_cast<unsigned long long>(s3),
-                   (s2 == sum && s3 == sum1) ? "(= dcb_core)" : "(DIFFERS from dcb_core)");
+                   (s2 == sum && s3 == sum1) ? "(= reference result)" : "(DIFFERS from the reference result)");
         }
         if (l.ns && l.ns_tl) {
             long long* tl = nullptr;
@@ -201,20 +209,21 @@ int main(int argc, char** argv)
             static const char* names[13] = {"prologue", "dc.3 mfma", "x + dc.3 epi + bar", "ffn0.0 mfma", "ffn0.1 mfma | epi 0", "ffn0.2 mfma | epi 1", "epi 2",
                                              "bar + ffn.2 mfma", "epi + bar", "y out", "dc.0 mfma", "epi + bar", "t1n out"};
             printf("  nsplit timeline (median cycles over workgroups):");
-            for (int i = 0; i < 13; ++i) {
+            const int nstamps = 10 + (CI >= 256 ? CI / 128 : CI / 64);     // see the stamp list in dcb_nsplit.hip
+            for (int i = 0; i < nstamps; ++i) {
                 std::vector<float> d;
                 for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && h[w * 32 + i + 1] != 0) d.push_back(static_cast<float>(h[w * 32 + i + 1] - h[w * 32 + i]));
-                printf(" %s %.0f |", names[i], median(d));
+                if (nstamps == 13) printf(" %s %.0f |", names[i], median(d)); else printf(" [%d] %.0f |", i + 1, median(d));
             }
             std::vector<float> tot, start;
             long long t0 = 0;
             for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && (t0 == 0 || h[w * 32] < t0)) t0 = h[w * 32];
-            for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0) { tot.push_back(static_cast<float>(h[w * 32 + 13] - h[w * 32])); start.push_back(static_cast<float>(h[w * 32] - t0)); }
+            for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0) { tot.push_back(static_cast<float>(h[w * 32 + nstamps] - h[w * 32])); start.push_back(static_cast<float>(h[w * 32] - t0)); }
             std::sort(start.begin(), start.end());
             printf(" total %.0f | workgroups %zu, start of the median / last workgroup %.0f / %.0f\n", median(tot), tot.size(),
                    start.empty() ? 0.f : start[start.size() / 2], start.empty() ? 0.f : start.back());
         }
-        if (l.tl) {
+        if (l.tl && has_core) {
             long long* tl = nullptr;
             const size_t rows = 1024;
             OK(hipMalloc(&tl, rows * 64 * 8));
