@@ -175,7 +175,7 @@ int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void*
     return dcvc::guarded([&] {
         dcvc::kernels_init();
         if (!dcvc::dcb_nsplit_shape(c, ci)) {
-            throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (384, 384), (512, 512), (512, 256) or (256, 128)");
+            throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256) or (256, 128)");
         }
         if (!w3 || !w0 || !w2) throw std::invalid_argument("dcb_nsplit: missing operand");
         dcvc::DcbNsplitDesc d;

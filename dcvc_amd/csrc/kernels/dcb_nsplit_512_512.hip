@@ -1,0 +1,13 @@
+// dcb_nsplit_kernel.h instantiated for block width 512, inner width 512
+#include "dcb_nsplit_kernel.h"
+
+namespace dcvc {
+namespace nsplit {
+
+void run_512_512(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream)
+{
+    run_shape<512, 512>(p, wide, next, dual, stream);
+}
+
+}  // namespace nsplit
+}  // namespace dcvc

@@ -85,7 +85,7 @@ void dcb_core(const DcbCoreDesc& d, hipStream_t stream);
 // The same block in "N-split" form (dcb_nsplit.hip, round 3): activations in LDS, every wave owns a quarter of
 // the output channels and streams ITS weight fragments straight from L2 out of a pre-packed per-wave stream
 // (dcb_nsplit_pack_main / _dc0, packed once at set_param time). (c, ci) = (block width, inner width cdc = cffn):
-// (384, 384), (512, 512), and the half-width `dcb2` blocks (512, 256), (256, 128). Bit-identical to dcb_core and to
+// (256, 256), (384, 384), (512, 512), (768, 768), and the half-width `dcb2` blocks (512, 256), (256, 128). Bit-identical to dcb_core and to
 // the launch sequence. y may alias x (a workgroup reads and writes only its own pixels).
 struct DcbNsplitDesc {
     const half_t* t2 = nullptr; int ldt = 0;

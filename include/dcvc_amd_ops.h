@@ -85,7 +85,7 @@ int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w
 /* The same operator (plus the inner width ci = cdc = cffn) through the N-split kernel (round 3: activations in LDS, every wave owns a quarter
  * of the output channels and streams its weight fragments from a packed copy of w3 | w0 | w2 [| w1n] that this entry point
  * builds on first use and caches per weight pointer - the codecs pack once at set_param time).
- * (c, ci) in {(384, 384), (512, 512)} - the full-width blocks dcvc_dcb_core serves - and {(512, 256), (256, 128)}: the
+ * (c, ci) in {(256, 256), (384, 384), (512, 512), (768, 768)} - full-width blocks - and {(512, 256), (256, 128)}: the
  * half-width `dcb2` blocks of the inter models (layers.py:128-159; w3 [c][ci], w0 [4 ci][c], w2 [c][ci], w1n [ci][c]).
  * Bit-identical to dcvc_dcb_core / dcvc_dcb_tail and to the separate launches. */
 int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,

@@ -561,6 +561,10 @@ def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inpla
     (256, 128, 32640, False, False, False, True, True),  # the low-delay model's dcb2 chains at P8
     (256, 128, 100, True, False, True, False, False),    # ... 32-pixel workgroups (the WSiLU table behind LDS padding)
     (256, 128, 20000, False, True, False, True, False),  # ... ragged, fused quant, next dc.0
+    (256, 256, 32640, False, False, False, True, True),  # the hierarchical models' reconstruction heads at P8
+    (256, 256, 510, True, False, True, False, False),    # ... their hyper networks at / 64
+    (768, 768, 8160, False, False, False, True, True),   # the hierarchical models' prior fusion at / 16 (32-pixel workgroups only)
+    (768, 768, 32400, True, False, True, False, False),  # ... at 3840x2160: still 32 pixels per workgroup (LDS)
 ])
 def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, nxt, inplace):
     """The same block through kernels/dcb_nsplit.hip (round 3: activations in LDS, every wave streams its quarter of
