@@ -119,13 +119,12 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     // (768-wide blocks - the hierarchical models' prior fusion at / 16 - have LDS for 32 pixels only)
     const bool wide = d.pixels >= 64 * 200 && d.c < 768;
     const bool next = d.wnext != nullptr;
-    static const int dual = [] { const char* e = getenv("DCVC_NSPLIT_DUAL"); return e != nullptr ? atoi(e) : 0; }();
-    if (d.c == 384) run_384_384(p, wide, next, dual != 0, stream);
-    else if (d.c == 768) run_768_768(p, wide, next, dual != 0, stream);
-    else if (d.c == 512 && d.ci == 512) run_512_512(p, wide, next, dual != 0, stream);
-    else if (d.c == 512) run_512_256(p, wide, next, dual != 0, stream);
-    else if (d.ci == 256) run_256_256(p, wide, next, dual != 0, stream);
-    else run_256_128(p, wide, next, dual != 0, stream);
+    if (d.c == 384) run_384_384(p, wide, next, stream);
+    else if (d.c == 768) run_768_768(p, wide, next, stream);
+    else if (d.c == 512 && d.ci == 512) run_512_512(p, wide, next, stream);
+    else if (d.c == 512) run_512_256(p, wide, next, stream);
+    else if (d.ci == 256) run_256_256(p, wide, next, stream);
+    else run_256_128(p, wide, next, stream);
 }
 
 }  // namespace dcvc

@@ -4,9 +4,9 @@
 namespace dcvc {
 namespace nsplit {
 
-void run_256_256(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream)
+void run_256_256(const NsParams& p, bool wide, bool next, hipStream_t stream)
 {
-    run_shape<256, 256>(p, wide, next, dual, stream);
+    run_shape<256, 256>(p, wide, next, stream);
 }
 
 }  // namespace nsplit

@@ -4,9 +4,9 @@
 namespace dcvc {
 namespace nsplit {
 
-void run_768_768(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream)
+void run_768_768(const NsParams& p, bool wide, bool next, hipStream_t stream)
 {
-    run_shape<768, 768>(p, wide, next, dual, stream);
+    run_shape<768, 768>(p, wide, next, stream);
 }
 
 }  // namespace nsplit

@@ -111,15 +111,13 @@ __device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
-template <int C, int CI, int PXT, bool NEXT, bool DUAL>
-__global__ void __launch_bounds__(NTHREADS, DUAL ? 2 : 1)
+template <int C, int CI, int PXT, bool NEXT>
+__global__ void __launch_bounds__(NTHREADS, 1)
 dcb_nsplit_kernel(const NsParams p)
 {
-    static_assert(!DUAL || PXT == 1, "two workgroups per CU: 32 pixels each");
     using G = Geo<C, CI>;
     // 512-wide layers x 64 pixels: 8 accumulator tiles per layer + 2 x 8 per ffn.0 pass leave room for 8 fragments in flight
-    // (DUAL: 256 registers per wave)
-    constexpr int RING = DUAL ? 12 : (C == 512 && PXT == 2) ? 8 : RING_DEFAULT;
+    constexpr int RING = (C == 512 && CI == 512 && PXT == 2) ? 8 : RING_DEFAULT;
     constexpr int PX = 32 * PXT;
     constexpr int KS_C = G::KS_C, KS_I = G::KS_I, MT_C = G::MT_C, MT_I = G::MT_I, NP = G::NP, TP = G::TP;
     constexpr int CH_C = C / 8, CH_I = CI / 8;                  // 16-byte chunks per row
@@ -245,12 +243,29 @@ dcb_nsplit_kernel(const NsParams p)
     };
     using ChI = std::integral_constant<int, CH_I>;
     using ChC = std::integral_constant<int, CH_C>;
-    // first tile: t2 -> A, then the first weight fragments; everything (constants included) is waited for in full
+    // ---- the block input x of a tile (dc.3's residual) waits in registers, in the layout of dc.3's epilogue: 16-byte
+    // runs of this lane's pixel
+    half8 xr[MT_C][PXT][2];
+    int pxv = px, hiv = hi;          // (made opaque once per tile: see the loop head)
+    auto load_x = [&](int first_row) {
+#pragma unroll
+        for (int t = 0; t < PXT; ++t) {
+            const half_t* const row = p.x + static_cast<size_t>(min(first_row + 32 * t + pxv, p.M - 1)) * p.ldx + (32 * MT_C * wave + 8 * hiv);
+#pragma unroll
+            for (int j = 0; j < MT_C; ++j)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) xr[j][t][pr] = *reinterpret_cast<const half8*>(row + 32 * j + 16 * pr);
+        }
+    };
+    // first tile: t2 -> A, then the first weight fragments, then x (dc.3's epilogue is its first use): everything in
+    // front of x (the constants included) is waited for here
     dma_tile(ChI{}, p.t2, p.ldt, 0, m0);
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, RING>([&](auto i) { issue(i); });
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load_x(m0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT_C * PXT * 2) : "memory");
     {
         float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
         t[tid] = tab0; t[tid + NTHREADS] = tab1; t[tid + 2 * NTHREADS] = tab2; t[tid + 3 * NTHREADS] = tab3;
@@ -359,17 +374,21 @@ dcb_nsplit_kernel(const NsParams p)
     };
 
     // ================================================================ persistent loop over this workgroup's tiles
-    // (tile, tile + gridDim.x, ...). The constants above are loaded once; t2 of the NEXT tile travels into A while this
-    // tile's dc.0 (or its tail) runs, x of this tile into B behind dc.3's MFMAs: only the first tile's t2 is exposed
-    // (as a kernel of one tile per workgroup the prologue was 12 k of 87 k cycles, profiles/r03_nsplit_ablation.txt).
+    // (tile, tile + gridDim.x, ...). The constants above are loaded once; t2 of the NEXT tile is requested right behind
+    // ffn.2's MFMAs of this one (into A, dead by then), its x (into registers) behind dc.0's MFMAs - each in front of an
+    // epilogue + row copy of 7 - 8 k cycles: only the first tile's transfers are exposed (as a kernel of one tile per workgroup
+    // the prologue was 12 k of 87 k cycles, profiles/r03_nsplit_ablation.txt). The PLACE matters: memory operations
+    // retire in order, so a transfer from HBM / the Infinity Cache issued in front of a contraction holds up every weight
+    // fragment (an L2 hit) requested behind it - with t2 in front of dc.0 and x in front of dc.3 those two contractions
+    // took 11.4 k and 7.9 k cycles instead of 5.7 k (profiles/r03_core_bench_dual0.txt).
     for (;;) {
     // Everything the unrolled body addresses hangs off these few per-lane values. Made opaque once per tile: as loop
     // invariants the compiler hoists EVERY derived address out of the loop (one register pair per weight fragment,
     // one register per LDS fragment: 1 000+ values) and spills them all (measured: 1 023 spilled registers).
-    asm volatile("" : "+v"(wsm), "+v"(wsn), "+v"(tab), "+v"(s0), "+v"(rowA), "+v"(rowB), "+v"(hi4), "+v"(tidv));
-    // x -> B: B is free (first tile: untouched; later: the previous tile's row copy is behind a barrier)
-    dma_tile(ChC{}, p.x, p.ldx, OFF_B, m0);
-    // ================================================================ dc.3: y1 = W3 t2 + b3' + x   (A -> B in place of x)
+    asm volatile("" : "+v"(wsm), "+v"(wsn), "+v"(tab), "+v"(s0), "+v"(rowA), "+v"(rowB), "+v"(hi4), "+v"(tidv), "+v"(pxv), "+v"(hiv));
+    const int next_tile = tile + static_cast<int>(gridDim.x);
+    const bool has_next = next_tile < ntiles;
+    // ================================================================ dc.3: y1 = W3 t2 + b3' + x   (A -> B)
     {
         float16v acc[MT_C][PXT];
 #pragma unroll
@@ -377,11 +396,6 @@ dcb_nsplit_kernel(const NsParams p)
 #pragma unroll
             for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT_C + j));
         contract(TagMTC{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc, no_piece);
-        // x: this wave's pieces are older than weight fragments it has already consumed (retired in order), the
-        // barrier covers the other waves' pieces
-        static_assert(G::F_DC3 >= RING, "dc.3 must issue at least RING fragments behind the x transfer");
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING) : "memory");
-        __syncthreads();
         stamp();
 #pragma unroll
         for (int j = 0; j < MT_C; ++j)
@@ -391,12 +405,10 @@ dcb_nsplit_kernel(const NsParams p)
                 for (int pr = 0; pr < 2; ++pr) {
                     float v[8];
                     runs_of(acc[j][t], pr, v);
-                    half8* const slot = run_b(t, 32 * (wave * MT_C + j) + 16 * pr);
-                    const half8 xr = *slot;
                     half8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[e]));
-                    *slot = o;
+                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[j][t][pr][e]));
+                    *run_b(t, 32 * (wave * MT_C + j) + 16 * pr) = o;
                 }
     }
     __syncthreads();            // y1 complete in B; every wave is done with t2 in A
@@ -411,8 +423,7 @@ dcb_nsplit_kernel(const NsParams p)
     // is exposed.
     {
         constexpr int NHC = 2 * TP * PXT;                 // half-tiles of a pass: (t, np, h, half)
-        // DUAL: the other workgroup of the CU fills the MFMA pipe while this one runs its epilogue: no second set
-        constexpr bool PIPE = NP > 1 && !DUAL;
+        constexpr bool PIPE = NP > 1;
         float16v accs[PIPE ? 2 : 1][TP][PXT];
         float4v crow[8];                                  // (plain vectors: an array of float4 structs went through scratch)
         float sums[2][4];                                 // [h][g] of the (t, np) pair being finished
@@ -484,8 +495,7 @@ dcb_nsplit_kernel(const NsParams p)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) sums[h][g] = a[2 * np + h][t][4 * g];
 #else
-                        // all 16 gathers of a tile in flight before its polynomials (DUAL: 8, registers)
-                        constexpr int GB = DUAL ? 8 : 16;
+                        constexpr int GB = 16;        // gathers in flight
 #pragma unroll
                         for (int g0 = 0; g0 < 16; g0 += GB) {
                             float4v c[GB];
@@ -546,6 +556,12 @@ dcb_nsplit_kernel(const NsParams p)
             for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT_C + j));
         contract(TagMTC{}, KsI{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, frag_a, acc, no_piece);
         stamp();
+        // the next tile's transfers (see the loop head): t is dead once every wave is behind its last ffn.2 MFMA
+        __syncthreads();
+        if (has_next) dma_tile(ChI{}, p.t2, p.ldt, 0, next_tile * PX);
+        // (unconditional - rows are clamped to the picture -: a conditional load keeps the old values alive)
+        if constexpr (!NEXT) load_x(next_tile * PX);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < MT_C; ++j)
 #pragma unroll
@@ -585,10 +601,6 @@ dcb_nsplit_kernel(const NsParams p)
     stamp();
     copy_out(ChC{}, bufB, PITCH_C, p.y, p.ldy);
     stamp();
-    const int next_tile = tile + static_cast<int>(gridDim.x);
-    const bool has_next = next_tile < ntiles;
-    // t2 of the next tile -> A: t (A) is dead, every wave is behind the barrier that follows ffn.2's epilogue
-    if (has_next) dma_tile(ChI{}, p.t2, p.ldt, 0, next_tile * PX);
 
     // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')   (B -> B)
     if constexpr (NEXT) {
@@ -606,6 +618,9 @@ dcb_nsplit_kernel(const NsParams p)
         }
         stamp();
         __syncthreads();        // every wave is done with y as an operand (and with copying it out): B becomes the staging area
+        // x of the next tile: a second burst of its own (all CUs ask at the same moment: 12 MB at 1080p), under this epilogue
+        load_x(next_tile * PX);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < MT_I; ++j)
 #pragma unroll
@@ -639,7 +654,7 @@ dcb_nsplit_kernel(const NsParams p)
     }
     if (!has_next) break;
     // the next tile's t2 has landed (every wave waits for its own pieces, the barrier covers the others'), the rows
-    // copied out of B are read: B is free for the next tile's x
+    // copied out of B are read: B is free for the next tile's y1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     tile = next_tile;
@@ -652,12 +667,12 @@ constexpr int smem_bytes()
     return align16k(32 * PXT * (C + CI) * 2) + R * TABLE_BYTES + (2 * C + 5 * CI) * 4 + 2 * C * 2;
 }
 
-template <int C, int CI, int PXT, bool NEXT, bool DUAL = false>
+template <int C, int CI, int PXT, bool NEXT>
 void launch(const NsParams& p, hipStream_t stream)
 {
-    auto kern = dcb_nsplit_kernel<C, CI, PXT, NEXT, DUAL>;
+    auto kern = dcb_nsplit_kernel<C, CI, PXT, NEXT>;
     constexpr int smem = smem_bytes<C, CI, PXT>();
-    static_assert(smem * (DUAL ? 2 : 1) <= 160 * 1024, "LDS budget");
+    static_assert(smem <= 160 * 1024, "LDS budget");
     static std::once_flag once;
     std::call_once(once, [&] {
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
@@ -671,8 +686,7 @@ void launch(const NsParams& p, hipStream_t stream)
         return n > 0 ? n : 256;
     }();
     const int tiles = (p.M + 32 * PXT - 1) / (32 * PXT);
-    const int slots = cus * (DUAL ? 2 : 1);
-    const int grid = tiles < slots ? tiles : slots;
+    const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;
     // 2 * pixels * C * kflop = FLOPs of the launch: dc.3 CI + ffn.0 4 CI + ffn.2 CI (+ dc.0 CI) per output channel of width C
     const int kflop = (NEXT ? 7 : 6) * CI;
@@ -685,13 +699,12 @@ void launch(const NsParams& p, hipStream_t stream)
 }
 
 // every instantiation of one block shape: 64 / 32 pixels per workgroup (768-wide blocks have LDS for 32 only), with /
-// without the next block's dc.0, and - where two workgroups fit into a CU's LDS - the DUAL form of the 32-pixel kernel
+// without the next block's dc.0. (Two 32-pixel workgroups per CU instead of one of 64 - 256 registers per wave, no
+// second accumulator set - were measured and are slower for every shape but (256, 128): 101.7 vs 94.8 us at (384, 384),
+// profiles/r03_core_bench_dual{0,1}.txt; git history has the kernel switch.)
 template <int C, int CI>
-void run_shape(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream)
+void run_shape(const NsParams& p, bool wide, bool next, hipStream_t stream)
 {
-    if constexpr (2 * smem_bytes<C, CI, 1>() <= 160 * 1024) {
-        if (wide && dual) { if (next) launch<C, CI, 1, true, true>(p, stream); else launch<C, CI, 1, false, true>(p, stream); return; }
-    }
     if constexpr (C < 768) {
         if (wide) { if (next) launch<C, CI, 2, true>(p, stream); else launch<C, CI, 2, false>(p, stream); return; }
     }
@@ -699,12 +712,12 @@ void run_shape(const NsParams& p, bool wide, bool next, bool dual, hipStream_t s
 }
 
 // dcb_nsplit_<shape>.hip
-void run_256_128(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream);
-void run_256_256(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream);
-void run_384_384(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream);
-void run_512_256(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream);
-void run_512_512(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream);
-void run_768_768(const NsParams& p, bool wide, bool next, bool dual, hipStream_t stream);
+void run_256_128(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_256_256(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_384_384(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_512_256(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_512_512(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_768_768(const NsParams& p, bool wide, bool next, hipStream_t stream);
 
 }  // namespace nsplit
 }  // namespace dcvc
