@@ -341,7 +341,8 @@ def cpu_baseline(cpu_net):
 
 
 TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
-KERNEL_SOURCES = ("dcb_core.hip", "conv_gemm.hip", "dcb_tail.hip", "ffn_fused.hip", "dwconv.hip", "arith.h")
+KERNEL_SOURCES = ("dcb_nsplit_kernel.h", "dcb_nsplit.hip", "dcb_core.hip", "conv_gemm.hip", "dcb_tail.hip", "ffn_fused.hip", "dwconv.hip",
+                  "arith.h")
 
 
 def kernel_source_digest():
@@ -425,13 +426,20 @@ def roofline(work, n=len(QPS)):
     for f, name in KERNEL_NAMES.items():
         sel = family == f
         if f == 4:
-            # one entry per template instantiation of the N-split block kernel: <C, pixels per workgroup> follows from (N, M)
-            for (m, c) in sorted({(int(a), int(b)) for a, b in zip(buf["M"][sel], buf["N"][sel])}):
-                one = sel & (buf["M"] == m) & (buf["N"] == c)
-                wide = m >= 64 * 200
-                k = part(one, "%s<%d, %d px>" % (name, c, 64 if wide else 32), (4 * m * c * 2 + 7 * c * c * 2) if c == 384 else None)
+            # one entry per shape of the N-split block kernel: <C, CI, pixels per workgroup> follows from (N, K, M): K = 7 CI
+            # with the next block's dc.0 inside the launch, 6 CI without (dcb_nsplit_kernel.h launch())
+            inner = {k * ci: ci for ci in (128, 256, 384, 512, 768) for k in (6, 7)}
+            shapes = sorted({(int(a), int(b), inner[int(c)]) for a, b, c in zip(buf["M"][sel], buf["N"][sel], buf["K"][sel])})
+            for (m, c, ci) in shapes:
+                one = sel & (buf["M"] == m) & (buf["N"] == c) & ((buf["K"] == 6 * ci) | (buf["K"] == 7 * ci))
+                nxt = float((buf["K"][one] == 7 * ci).mean())            # share of the launches with the next dc.0
+                wide = m >= 64 * 200 and c < 768
+                # every operand once: t2 [M][CI], x [M][C] in, y [M][C] (and t1' [M][CI]) out, the block's weights
+                alg = 2 * m * (2 * c + ci + nxt * ci) + 2 * c * ci * (6 + nxt)
+                k = part(one, "%s<%d, %d, %d px>" % (name, c, ci, 64 if wide else 32), alg)
                 if k:
                     k["pixels"] = m
+                    k["with_next_dc0"] = nxt
                     kernels.append(k)
             continue
         k = part(sel, name, core_bytes if f == 1 else None)
@@ -439,7 +447,7 @@ def roofline(work, n=len(QPS)):
             kernels.append(k)
     total_ms, total_fl = float(buf["ms"].sum()), float(flops.sum())
     dom = max(kernels, key=lambda k: k["ms_per_step"])
-    traffic, source = pmc_traffic(dom["kernel"].split("<")[0])
+    traffic, source = pmc_traffic(dom["kernel"])
     return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": dom["frac"], "traffic": traffic, "traffic_source": source,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],

@@ -6,13 +6,23 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
 FAMILIES = ("dcb_core_kernel", "conv_gemm_kernel", "dwconv3x3_kernel", "dcb_tail_kernel", "ffn_fused_kernel")
+NSPLIT = re.compile(r"dcb_nsplit_kernel<(\d+), (\d+), (\d+), (true|false)>")
+NSPLIT_MANGLED = re.compile(r"dcb_nsplit_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E")
 
 
 def family(name):
+    """the key bench.py's roofline uses for the kernel: the N-split block kernel per shape <C, CI, pixels per workgroup>
+    (launches with and without the next block's dc.0 together), the others by name"""
+    m = NSPLIT.search(name) or NSPLIT_MANGLED.search(name)
+    if m:
+        return "dcb_nsplit_kernel<%s, %s, %d px>" % (m.group(1), m.group(2), 32 * int(m.group(3)))
     for f in FAMILIES:
         if f in name:
             return f
@@ -37,13 +47,14 @@ def collect(root, counter):
 
 def main():
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    import bench
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 5 --warmup 3 "
-                     "--no-cpu-baseline --no-roofline --no-extras (separate passes); FETCH_SIZE doubled per "
+                     "--no-cpu-baseline --no-roofline --no-extras --no-uhd (separate passes); FETCH_SIZE doubled per "
                      "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), counter units KB",
-           "commit": sys.argv[4] if len(sys.argv) > 4 else None, "kernels": {}}
-    for fam in FAMILIES:
-        if fam not in fetch and fam not in write:
-            continue
+           "commit": sys.argv[4] if len(sys.argv) > 4 else None,
+           # bench.py reports these numbers only while the kernel sources are the ones measured here
+           "kernel_source_digest": bench.kernel_source_digest(), "kernels": {}}
+    for fam in sorted(set(fetch) | set(write)):
         f, w = fetch.get(fam, [0.0, 0]), write.get(fam, [0.0, 0])
         fb = 2.0 * 1024.0 * f[0] / max(f[1], 1)
         wb = 1024.0 * w[0] / max(w[1], 1)
