@@ -508,6 +508,9 @@ def main():
         work = FanoutWorkload(args.workload, device, pics, gpu_net, pad_b, pad_r, dist)
     else:
         work = make_work(args.workload, height, width)
+    if os.environ.get("DCVC_BENCH_GRAPHS") in ("0", "1"):     # A/B of the codecs' launch mode (hipGraph replay / eager)
+        work.default_graphs = os.environ["DCVC_BENCH_GRAPHS"] == "1"
+        work.set_use_graphs(work.default_graphs)
     # independent streams: rank r codes the steps shard_range() gives it out of world * steps (weak scaling,
     # no data-path collective); fan-out: every rank takes part in every step
     from dcvc_amd import sharding
