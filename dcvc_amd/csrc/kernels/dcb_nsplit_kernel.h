@@ -1,4 +1,4 @@
-// dcb_nsplit.hip - a full-width DepthConvBlock behind its depthwise conv in ONE launch, "N-split" form:
+// dcb_nsplit_kernel.h - a DepthConvBlock behind its depthwise conv in ONE launch, "N-split" form:
 //
 //     y1 = W3 * t2 + b3' + x                          dc.3 (+ folded depthwise bias) + block input
 //     t  = chunk_add(WSiLU(W0 * y1 + b0))             ffn.0   (4x expansion, never materialised)
@@ -16,14 +16,15 @@
 // matrix cores need 64 k. Here the roles are swapped:
 //
 //   * a workgroup owns PX = 32 * PXT pixels (64 at picture resolution / 8), whose activations live in LDS
-//     (two [PX][C] fp16 buffers, XOR-swizzled 16-byte chunks: layer input and layer output ping-pong);
+//     (A = [PX][CI], B = [PX][C] fp16, XOR-swizzled 16-byte chunks: layer input and layer output ping-pong);
 //   * a wave owns a QUARTER OF THE OUTPUT CHANNELS of every layer and all PX pixels: its weight fragments
 //     come straight from L2 into registers (global_load_dwordx4 of a pre-packed, per-wave linear stream: one
 //     contiguous KB per MFMA "A" operand, prefetched 16 fragments = 4 k-slices ahead), every fragment feeds PXT
 //     MFMAs, activation ("B") fragments are PXT ds_read_b128 per k-slice for 3-4 * PXT MFMAs;
 //   * no barrier inside a layer (4 per block), no LDS-DMA in the main loop, the waves drift apart freely;
-//   * inputs arrive as whole rows (LDS-DMA in the prologue), outputs leave as whole rows (epilogue -> LDS ->
-//     coalesced 16-byte stores): HBM sees full 128-byte lines only.
+//   * workgroups are persistent (one per CU, tiles round-robin): constants once, the next tile's t2 (whole rows by
+//     LDS-DMA) and x (registers) requested behind the current tile's last contractions; outputs leave straight from
+//     the epilogues' registers (NS_DIRECT).
 //   Cost: every workgroup streams the block's weights itself (2 MB per 64 pixels from L2 instead of per 128) -
 //   64 B/clk/CU at full matrix-core rate, the L1 fill rate; L2-resident because every CU streams the same bytes.
 //
@@ -122,7 +123,7 @@ dcb_nsplit_kernel(const NsParams p)
     constexpr int KS_C = G::KS_C, KS_I = G::KS_I, MT_C = G::MT_C, MT_I = G::MT_I, NP = G::NP, TP = G::TP;
     constexpr int CH_C = C / 8, CH_I = CI / 8;                  // 16-byte chunks per row
     constexpr int PITCH_C = C * 2, PITCH_I = CI * 2;
-    // A: [PX][CI] (t2, then t); B: [PX][C] (x, y1, y; then the staged t1' rows, CI wide)
+    // A: [PX][CI] (t2, then t); B: [PX][C] (y1, then y as dc.0's operand)
     constexpr int BUF_A = PX * PITCH_I, BUF_B = PX * PITCH_C;
     constexpr int OFF_B = BUF_A;
     constexpr int OFF_TABLE = align16k(BUF_A + BUF_B);
@@ -131,6 +132,15 @@ dcb_nsplit_kernel(const NsParams p)
     constexpr int BIAS_FLOATS = 2 * C + 5 * CI;
     constexpr int OFF_Q = OFF_BIAS + BIAS_FLOATS * 4;               // fp16: q | q2
     constexpr int TOTAL = G::F_MAIN + (NEXT ? G::F_DC0 : 0);
+#ifndef NS_DIRECT
+#define NS_DIRECT 3
+#endif
+    // Output rows (bit 0: t1', bit 1: y) are stored straight from the epilogues' registers - 16 bytes per lane, half-waves
+    // pairing up to 32-byte pieces of a row, L2 merges the pieces of a line - instead of staged in LDS, synchronised and
+    // copied out as whole rows: a barrier and a 2 k-cycle copy less per output (A/B on one box, tools/r3_session17.sh:
+    // intra 80.8 -> 83.8, HT-S 430 -> 443 pictures/s on a throttled box; every shape of the block bench equal or faster).
+    // NS_DIRECT=0 builds the staged form.
+    constexpr bool DIRECT_T1 = (NS_DIRECT & 1) != 0, DIRECT_Y = (NS_DIRECT & 2) != 0;
     static_assert((PX * CH_C) % NTHREADS == 0 && (PX * CH_I) % NTHREADS == 0, "tile rows must split evenly over the threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -594,12 +604,17 @@ dcb_nsplit_kernel(const NsParams p)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
                     }
-                    *slot = o;
+                    if constexpr (NEXT || !DIRECT_Y) *slot = o;          // dc.0's operand
+                    if constexpr (DIRECT_Y) {
+                        // 16 bytes per lane straight from the registers (half-waves pair up to 32-byte pieces of a row)
+                        const int m = m0 + 32 * t + pxv;
+                        if (m < p.M) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
+                    }
                 }
     }
-    __syncthreads();            // y complete in B; every wave is done with t in A
+    if constexpr (NEXT || !DIRECT_Y) __syncthreads();            // y complete in B; every wave is done with t in A
     stamp();
-    copy_out(ChC{}, bufB, PITCH_C, p.y, p.ldy);
+    if constexpr (!DIRECT_Y) copy_out(ChC{}, bufB, PITCH_C, p.y, p.ldy);
     stamp();
 
     // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')   (B -> B)
@@ -617,7 +632,7 @@ dcb_nsplit_kernel(const NsParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp();
-        __syncthreads();        // every wave is done with y as an operand (and with copying it out): B becomes the staging area
+        if constexpr (!DIRECT_T1) __syncthreads();        // every wave is done with y as an operand (and with copying it out): B becomes the staging area
         // x of the next tile: a second burst of its own (all CUs ask at the same moment: 12 MB at 1080p), under this epilogue
         load_x(next_tile * PX);
         __builtin_amdgcn_sched_barrier(0);
@@ -638,12 +653,17 @@ dcb_nsplit_kernel(const NsParams p)
                     half8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], make_float4(c[e][0], c[e][1], c[e][2], c[e][3])));
-                    // staged with B's pitch, the CI channels in the first CI / 8 chunks of a row
-                    *run_b(t, 32 * (wave * MT_I + j) + 16 * pr) = o;
+                    if constexpr (DIRECT_T1) {
+                        const int m = m0 + 32 * t + pxv;
+                        if (m < p.M) store_line(p.t1n + static_cast<size_t>(m) * p.ldt1 + 32 * (wave * MT_I + j) + 16 * pr + 8 * hiv, o);
+                    } else {
+                        // staged with B's pitch, the CI channels in the first CI / 8 chunks of a row
+                        *run_b(t, 32 * (wave * MT_I + j) + 16 * pr) = o;
+                    }
                 }
-        __syncthreads();
+        if constexpr (!DIRECT_T1) __syncthreads();
         stamp();
-        copy_out(ChI{}, bufB, PITCH_C, p.t1n, p.ldt1);
+        if constexpr (!DIRECT_T1) copy_out(ChI{}, bufB, PITCH_C, p.t1n, p.ldt1);
         stamp();
     } else {
         if (has_next) {
