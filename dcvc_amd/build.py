@@ -92,6 +92,23 @@ def build(force=False, verbose=False):
         with open(manifest) as f:
             if f.read().strip() == digest:
                 return LIB
+    # several ranks of one node may get here at once (bench.py --gpus N on a box whose library is stale): one builds,
+    # the others wait for the lock and find the library current
+    import fcntl
+    lock = open(LIB + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _build_locked(force, verbose, srcs, manifest, digest)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(force, verbose, srcs, manifest, digest):
+    if not force and os.path.exists(LIB) and os.path.exists(manifest) and os.path.exists(CLI_BIN):
+        with open(manifest) as f:
+            if f.read().strip() == digest:
+                return LIB
     hdr_digest = _digest(_headers())
     jobs = []
     objs = []
