@@ -599,11 +599,13 @@ void dcb_tail_debug_buffer(half_t* device_buffer)
 bool dcb_tail_supported(int H, int W, int c, int cdc, int cffn)
 {
     // DCVC_DCB_TAIL: 0 = never, 2 = whenever the shape allows (parity tests on small pictures),
-    // unset / 1 = when the patches fill the chip, 3 = like 1 but dc.0 stays a launch of its own (A/B)
+    // unset / 1 = when the patches fill the chip (128-wide blocks: always), 3 = like 1 but dc.0 stays a launch of its own (A/B)
     static const int mode = [] { const char* e = getenv("DCVC_DCB_TAIL"); return e != nullptr ? atoi(e) : 1; }();
     if (mode == 0 || H <= 0 || W <= 0 || !shape_ok(c, cdc, cffn)) return false;
     const int patches = ((H + PH - 1) / PH) * ((W + PW - 1) / PW);
-    return mode == 2 || patches >= 192;
+    // the 128-wide blocks (LD's hyper networks at / 16 .. / 64: 72 patches and fewer) are pure launch latency either way:
+    // one launch instead of five (LD 1080p 313 -> 319 pictures/s, DCVC_DCB_TAIL=1 vs 2 in tools/r3_session19.sh)
+    return mode == 2 || patches >= 192 || c <= 128;
 }
 
 bool dcb_tail_takes_dc0()
