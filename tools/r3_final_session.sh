@@ -8,7 +8,7 @@ R=$PWD
 B=tools/_bin
 L=dcvc_amd/libdcvc_amd.so
 # a throttled box (seen once: everything 1.7x slower) is not worth the GPU minutes: check the block kernel first
-us=$(timeout 120 $B/core_bench -r 2 -n 10 $L | grep "dcb_nsplit + next" | head -1 | awk '{print $7}')
+us=$(timeout 120 $B/core_bench -r 2 -n 10 $L | grep "dcb_nsplit + next" | head -1 | awk '{print $5}')
 echo "block kernel: $us us"
 if [ -z "$us" ] || awk -v u="$us" 'BEGIN { exit !(u > 105) }'; then echo "SLOW BOX - stopping"; exit 7; fi
 BENCH="python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --no-uhd --min-seconds 0"
