@@ -143,16 +143,27 @@ def test_inter_matches_oracle_digest(name):
 
 
 @pytest.mark.timeout(900)
-def test_launch_sequence_path_matches_the_digests():
-    """The same digests with the block kernels switched off (DCVC_NO_DCB_CORE=1: every DepthConvBlock as its
-    launch sequence dc.0 | depthwise | dc.3 | ffn.0 | ffn.2 through conv_gemm): both paths are the same arithmetic,
-    operation for operation. The switch is read once per process, hence the child process."""
+@pytest.mark.parametrize("switch,pick,count", [
+    # every DepthConvBlock as its launch sequence dc.0 | depthwise | dc.3 | ffn.0 | ffn.2 through conv_gemm
+    ("DCVC_NO_DCB_CORE", "dmci_1920x1080_q32_t0.15 or dmci_1920x1080_q63_t0.0 or dmci_1280x720_q0_t0.15 or dmci_256x256 or "
+                         "ld_1280x720 or hts_1280x720 or htl_1280x720", 7),
+    # round 2's kernels instead of dcb_nsplit: dcb_core (C = 384), dcb_tail / ffn_fused (half-width blocks)
+    ("DCVC_NSPLIT", "dmci_1280x720_q32_t0.15 or ld_1280x720 or hts_1280x720 or htl_1280x720", 4),
+])
+def test_other_kernel_paths_match_the_digests(switch, pick, count):
+    """The same digests with the block kernels switched off (DCVC_NO_DCB_CORE=1) and with round 2's block kernels in
+    place of dcb_nsplit (DCVC_NSPLIT=0): all paths are the same arithmetic, operation for operation. The switches are
+    read once per process, hence the child process."""
     import subprocess
     import sys
-    if os.environ.get("DCVC_NO_DCB_CORE"):
-        pytest.skip("already the launch-sequence path")
-    env = dict(os.environ, DCVC_NO_DCB_CORE="1")
-    pick = "dmci_1920x1080_q32_t0.15 or dmci_1920x1080_q63_t0.0 or dmci_1280x720_q0_t0.15 or dmci_256x256"
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", pick,
-                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=850)
-    assert res.returncode == 0 and "4 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]
+    if os.environ.get("DCVC_NO_DCB_CORE") or os.environ.get("DCVC_NSPLIT"):
+        pytest.skip("already on a switched path")
+    env = dict(os.environ)
+    if switch == "DCVC_NO_DCB_CORE":
+        env.update(DCVC_NO_DCB_CORE="1", DCVC_DCB_TAIL="0", DCVC_FFN_FUSED="0")     # no fused block kernel of any kind
+    else:
+        env[switch] = "0"
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "(%s) and not other_kernel_paths" % pick, "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=850)
+    assert res.returncode == 0 and "%d passed" % count in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]

@@ -565,6 +565,13 @@ def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inpla
     (256, 256, 510, True, False, True, False, False),    # ... their hyper networks at / 64
     (768, 768, 8160, False, False, False, True, True),   # the hierarchical models' prior fusion at / 16 (32-pixel workgroups only)
     (768, 768, 32400, True, False, True, False, False),  # ... at 3840x2160: still 32 pixels per workgroup (LDS)
+    # just below the 64-pixel threshold (1024x768 and the like: 12 288 pixels at / 8): 32-pixel tiles, MORE tiles than CUs,
+    # so the persistent workgroups walk several 32-pixel tiles each
+    (384, 384, 12288, False, True, False, True, True),
+    (512, 256, 12000, True, False, True, True, False),
+    (512, 512, 12700, False, False, False, True, True),
+    (256, 256, 12288, False, True, False, True, False),
+    (256, 128, 12001, True, False, False, True, False),
 ])
 def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, nxt, inplace):
     """The same block through kernels/dcb_nsplit.hip (round 3: activations in LDS, every wave streams its quarter of
