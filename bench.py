@@ -160,6 +160,14 @@ class IntraWorkload:
         for g in {id(self.net): self.net, id(self.dec): self.dec}.values():
             g._ensure_proxy().set_use_graphs(on)
 
+    def closure(self, i, qp):
+        """decoder reconstruction == encoder reconstruction, bit for bit (what the reference asserts nowhere but relies on)"""
+        enc = self.compress(i, qp)
+        want = enc["x_hat"].clone()             # proxy-owned buffer: the decode below may overwrite it
+        got = self.decompress(i, qp, enc)["x_hat"]
+        torch.cuda.synchronize()
+        return bool(torch.equal(got, want)) and bool(torch.isfinite(got.float()).all()) and len(enc["bit_stream"]) > 0
+
     default_graphs = True
 
 
@@ -214,6 +222,19 @@ class InterWorkload:
     def set_use_graphs(self, on):
         for g in (self.enc, self.dec):
             g._ensure_proxy().set_use_graphs(on)
+
+    def closure(self, i, qp):
+        """encoder / decoder lock-step: the decoder (which saw only the bytes) holds the very feature_p the encoder holds -
+        every reconstruction head reads nothing else (video_model_ht.py:252-275) - and finite in-range pictures"""
+        self.prepare(i)
+        enc = self.compress(i, qp)
+        xd = self.decompress(i, qp, enc)["x_hat"]
+        torch.cuda.synchronize()
+        xd = torch.cat(list(xd), 0) if isinstance(xd, (list, tuple)) else xd
+        fe = self.enc._ensure_proxy().debug_read("feature_p", np.float16)
+        fd = self.dec._ensure_proxy().debug_read("feature_p", np.float16)
+        return bool(np.array_equal(fe, fd)) and bool(torch.isfinite(xd.float()).all()) and float(xd.abs().max()) <= 0.5 \
+            and len(enc["bit_stream"]) > 0
 
 
 class FanoutWorkload(InterWorkload):
@@ -283,6 +304,12 @@ def call_times(work, first, n):
     return float(np.mean(enc_t[keep])), float(np.mean(dec_t[keep]))
 
 
+def closure_ok(work, first):
+    """After a timed region: one compress / decompress per rate point of QPS, checked (a throughput number from
+    a desynchronised codec would otherwise look like any other). Continues the workload's stream at step `first`."""
+    return all([work.closure(first + k, qp) for k, qp in enumerate(QPS)])
+
+
 def fps_block(work, first, steps, warmup, with_roofline=False):
     """throughput (pipelined loop) + the reference-style encode / decode rates of one workload"""
     run_steps(work, first, warmup)
@@ -291,10 +318,12 @@ def fps_block(work, first, steps, warmup, with_roofline=False):
     nbytes = run_steps(work, first + warmup, steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    te, td = call_times(work, first + warmup + steps, min(steps, 24) + DROP_CALLS)
+    ncalls = min(steps, 24) + DROP_CALLS
+    te, td = call_times(work, first + warmup + steps, ncalls)
     out = {"value": steps * work.frames / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
            "encode_fps": work.frames / te, "decode_fps": work.frames / td,
-           "bpp": 8.0 * nbytes / steps / work.frames / (work.height * work.width)}
+           "bpp": 8.0 * nbytes / steps / work.frames / (work.height * work.width),
+           "closure_ok": closure_ok(work, first + warmup + steps + ncalls)}
     if with_roofline:
         r = roofline(work, n=2)
         out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "all_contractions")}
@@ -549,11 +578,18 @@ def main():
         sustained = {"steps": more, "seconds": t_more, "value": (1 if fanout else world) * more * work.frames / t_more,
                      "unit": "frames/s"}
 
+    ncalls = min(args.steps, 32) + DROP_CALLS
     if fanout:       # every rank takes part in the per-call timing loop (the broadcast is a collective)
-        te, td = call_times(work, args.warmup + args.steps, min(args.steps, 32) + DROP_CALLS)
+        te, td = call_times(work, args.warmup + args.steps, ncalls)
+    # every rank checks ITS codec objects after the timed regions (fan-out: the shared stream is checked by the tests)
+    closure = None if fanout else closure_ok(work, args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0))
+    if dist is not None and closure is not None:
+        flag = torch.tensor([1.0 if closure else 0.0], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        closure = bool(flag.item() > 0.5)
     if rank == 0:
         if not fanout:
-            te, td = call_times(work, args.warmup + args.steps, min(args.steps, 32) + DROP_CALLS)
+            te, td = call_times(work, args.warmup + args.steps, ncalls)
         fps = (1 if fanout else world) * args.steps * work.frames / elapsed
         res = "%dx%d" % (width, height)
         out = {
@@ -577,6 +613,7 @@ def main():
                           "(events around each call on a synchronised device, first %d calls dropped, rank 0)" % DROP_CALLS,
             "bytes_per_picture": nbytes / args.steps / work.frames,
             "bpp": 8.0 * nbytes / args.steps / work.frames / (height * width),
+            "closure_ok": closure,
         }
         if sustained is not None:
             out["sustained"] = sustained

@@ -159,6 +159,15 @@ def cases(quick):
         c["hts_1920x1080"] = lambda: run_inter("hts", (1080, 1920), [(32, 0)], 0.15)
         c["htl_1920x1080"] = lambda: run_inter("htl", (1080, 1920), [(32, 0)], 0.15)
     c["ld_1280x720"] = lambda: run_inter("ld", (720, 1280), [(32, 0), (40, 1), (40, 0)], 0.15)
+    if not quick:
+        # round 4: the rate points at both ends of the range for the inter models (the full-size
+        # cases above code at q 32 / 40 / 45 only, bench.py cycles 0 ... 63), a second HT-L call WITH a memory reset,
+        # and the hierarchical models at 3840x2160 (BASELINE configs[4])
+        c["ld_qends_1280x720"] = lambda: run_inter("ld", (720, 1280), [(0, 0), (63, 0), (0, 1)], 0.15)
+        c["hts_qends_1280x720"] = lambda: run_inter("hts", (720, 1280), [(0, 0), (63, 0)], 0.15)
+        c["htl_qends_1280x720"] = lambda: run_inter("htl", (720, 1280), [(0, 0), (63, 1)], 0.15)
+        c["hts_3840x2160"] = lambda: run_inter("hts", (2160, 3840), [(32, 0)], 0.15)
+        c["htl_3840x2160"] = lambda: run_inter("htl", (2160, 3840), [(32, 0)], 0.15)
     c["hts_1280x720"] = lambda: run_inter("hts", (720, 1280), [(32, 0), (45, 1)], 0.15)
     return c
 

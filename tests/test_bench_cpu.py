@@ -75,6 +75,11 @@ class _FakeWork:
     def set_use_graphs(self, on):
         pass
 
+    def closure(self, i, qp):
+        self.closures = getattr(self, "closures", 0) + 1
+        self.decompress(i, qp, self.compress(i, qp))
+        return True
+
 
 class _FakeInter(_FakeWork):
     def __init__(self, kind, *a, **k):
@@ -140,6 +145,9 @@ def test_one_json_line_with_the_contract_fields(fake_gpu, monkeypatch, capsys):
     assert d["encode_fps"] > d["decode_fps"] > 0
     assert 1.3 < d["encode_fps"] / d["decode_fps"] < 2.8
     assert set(d["other_workloads"]) == {"ld", "hts", "htl"}
+    # closure (decoder output == encoder output for every rate point) is checked behind every timed region and reported
+    assert d["closure_ok"] is True and all(o["closure_ok"] is True for o in d["other_workloads"].values())
+    assert all(d["uhd"][k]["closure_ok"] is True for k in ("intra", "ld", "hts", "htl"))
     for kind, o in d["other_workloads"].items():
         assert set(o) >= {"value", "encode_fps", "decode_fps", "ms_per_step"} and o["value"] > 0
     assert d["other_workloads"]["hts"]["value"] > d["other_workloads"]["ld"]["value"]     # 8 pictures per call
@@ -184,7 +192,7 @@ def test_inter_workload_line(fake_gpu, monkeypatch, capsys):
 
 class _FakeDist:
     """stands in for torch.distributed inside bench.main(): one process plays one rank of a 2-GPU launch"""
-    ReduceOp = type("ReduceOp", (), {"MAX": "max"})
+    ReduceOp = type("ReduceOp", (), {"MAX": "max", "MIN": "min"})
 
     def __init__(self, rank, world):
         self.rank, self.world, self.barriers, self.reduced = rank, world, 0, 0
@@ -196,8 +204,11 @@ class _FakeDist:
         self.barriers += 1
 
     def all_reduce(self, t, op=None):
-        assert op == "max"
-        self.reduced += 1
+        assert op in ("max", "min")
+        if op == "max":
+            self.reduced += 1
+        else:
+            self.closure_votes = getattr(self, "closure_votes", 0) + 1      # every rank's closure flag, MIN over ranks
 
     def get_rank(self):
         return self.rank
@@ -227,6 +238,7 @@ def test_one_rank_of_a_two_gpu_launch(fake_gpu, monkeypatch, capsys, rank):
     timed = [c[1] for c in w.calls if c[0] == "c"][1:5]
     assert timed == [1 + 4 * rank + i for i in range(4)]          # warm-up step 0, then this rank's share of the 8 steps
     assert fake.barriers >= 3 and fake.reduced == 2          # the K timed steps and the sustained region
+    assert fake.closure_votes == 1 and w.closures == len(bench.QPS)          # every rank checks its own codec objects
     if rank == 1:
         assert lines == []
         return
@@ -252,6 +264,7 @@ def test_fan_out_line(fake_gpu, monkeypatch, capsys):
     bench.main()
     d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.strip()][0])
     assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["sharding"] == "recon-head fan-out"
+    assert d["closure_ok"] is None                          # the shared stream is covered by the fan-out tests, not here
     assert d["value"] == pytest.approx(8 * 3 / (d["ms_per_step"] * 3 / 1e3), rel=1e-6)
     assert "roofline" not in d
     with pytest.raises(SystemExit):

@@ -70,3 +70,9 @@ def test_ld_gop_closure_uhd():
 
 def test_hts_chunk_closure_uhd():
     _gop(dmc_ht_model("hts", skip_thres=0.15), 8, [(34, 0)])
+
+
+def test_htl_chunk_closure_uhd():
+    """HT-L at 3840x2160 (round 4; DESIGN claimed this test one round before it existed): two chunks, the second with a
+    memory reset - the 4-step entropy scheme of dmc_htl_proxy.cpp:624-689 on the 135 x 240 grid."""
+    _gop(dmc_ht_model("htl", skip_thres=0.15), 8, [(34, 0), (46, 1)])
