@@ -54,12 +54,22 @@ def _hipcc():
     return "hipcc"
 
 
+def _host_cxx():
+    for cand in (os.environ.get("CXX"), "/opt/rocm/lib/llvm/bin/clang++", "g++"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "g++"
+
+
 def _compile(src, obj, verbose):
     # ``.hip`` = anything that includes the HIP runtime (kernels and the host codec);
     # ``.cpp`` = plain host C++ (the rANS coder), still compiled by hipcc's clang.
-    cmd = [_hipcc(), "-c"] + COMMON
     if src.endswith(".hip"):
-        cmd += ["-x", "hip"] + HIP_FLAGS
+        cmd = [_hipcc(), "-c"] + COMMON + ["-x", "hip"] + HIP_FLAGS
+    else:
+        # host-only C++ straight through clang++ (the hipcc wrapper would compile a .cpp as HIP, device pass included:
+        # x86 target attributes and builtins - the AVX-512 path of the rANS decoder - do not exist there)
+        cmd = [_host_cxx(), "-c"] + COMMON
     cmd += ["-o", obj, src]
     if verbose:
         print(" ".join(cmd), flush=True)

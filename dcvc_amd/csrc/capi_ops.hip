@@ -1,6 +1,8 @@
 // C ABI of the individual kernels (include/dcvc_amd_ops.h).
 #include "capi_common.h"
+#include <memory>
 #include <mutex>
+#include <stdexcept>
 #include "dcvc_amd_ops.h"
 #include "kernels/ops.h"
 
@@ -139,31 +141,38 @@ int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w
 }
 
 namespace {
-// dcvc_dcb_nsplit takes the weights as the reference lays them out; the kernel wants its per-wave fragment streams.
-// Packed copies are cached per weight pointer (the codecs pack once at set_param time, dcvc::DcbW::load; this
-// cache serves the operator-level entry point: tests and tools). Bounded: the oldest entries are dropped.
-struct PackedEntry { const void* a; const void* b; const void* c; int width, inner; void* packed; };
-std::vector<PackedEntry> g_packed;
-std::mutex g_packed_mu;
+// The N-split kernel wants its per-wave fragment streams, not the reference's row-major matrices. The codecs pack once
+// at set_param time (dcvc::DcbW::load). The operator-level entry points below serve tests and tools:
+//   dcvc_dcb_nsplit          packs on EVERY call into stream-ordered temporaries (hipMallocAsync / hipFreeAsync on the
+//                            caller's stream): always reads the weights as they are now. (Round 3 cached packed copies per
+//                            weight POINTER: a caller that rewrote its weights in place, or whose allocator handed the same
+//                            address out again, silently got the old weights - advisor, round 3.)
+//   dcvc_dcb_nsplit_pack / _packed / _free   explicit handle for callers that launch many times (tools/probes/core_bench).
+struct NsplitPacked {
+    int c = 0, ci = 0, device = 0;
+    dcvc::half_t* main = nullptr;
+    dcvc::half_t* next = nullptr;
+};
 
-const dcvc::half_t* packed_for(const void* a, const void* b, const void* c, int width, int inner, bool dc0, hipStream_t st)
+void nsplit_check_shape(int c, int ci)
 {
-    std::lock_guard<std::mutex> lk(g_packed_mu);
-    for (const PackedEntry& e : g_packed) {
-        if (e.a == a && e.b == b && e.c == c && e.width == width && e.inner == inner) return static_cast<const dcvc::half_t*>(e.packed);
+    if (!dcvc::dcb_nsplit_shape(c, ci)) {
+        throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256) or (256, 128)");
     }
-    if (g_packed.size() >= 64) {
-        (void)hipDeviceSynchronize();
-        (void)hipFree(g_packed.front().packed);
-        g_packed.erase(g_packed.begin());
-    }
-    void* out = nullptr;
-    const size_t halves = dc0 ? dcvc::dcb_nsplit_dc0_halves(width, inner) : dcvc::dcb_nsplit_main_halves(width, inner);
-    dcvc::hip_check(hipMalloc(&out, halves * 2), "hipMalloc(packed weights)");
-    if (dc0) dcvc::dcb_nsplit_pack_dc0(H(a), width, inner, static_cast<dcvc::half_t*>(out), st);
-    else dcvc::dcb_nsplit_pack_main(H(a), H(b), H(c), width, inner, static_cast<dcvc::half_t*>(out), st);
-    g_packed.push_back(PackedEntry{a, b, c, width, inner, out});
-    return static_cast<const dcvc::half_t*>(out);
+}
+
+void nsplit_launch(const dcvc::half_t* wmain, const dcvc::half_t* wnext, const void* t2, int ldt, const void* x, int ldx,
+                   const void* b3, const void* b0, const void* b2, const void* q, const void* q2, const void* b1n,
+                   void* t1n, int ldt1, void* y, int ldy, int pixels, int c, int ci, int shortcut, hipStream_t st)
+{
+    dcvc::DcbNsplitDesc d;
+    d.t2 = H(t2); d.ldt = ldt; d.x = H(x); d.ldx = ldx;
+    d.wmain = wmain;
+    d.wnext = wnext;
+    d.b3 = H(b3); d.b0 = H(b0); d.b2 = H(b2); d.b1n = H(b1n); d.q = H(q); d.q2 = H(q2);
+    d.t1n = H(t1n); d.ldt1 = ldt1; d.y = H(y); d.ldy = ldy;
+    d.pixels = pixels; d.c = c; d.ci = ci; d.shortcut = shortcut != 0;
+    dcvc::dcb_nsplit(d, st);
 }
 }  // namespace
 
@@ -174,18 +183,81 @@ int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void*
 {
     return dcvc::guarded([&] {
         dcvc::kernels_init();
-        if (!dcvc::dcb_nsplit_shape(c, ci)) {
-            throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256) or (256, 128)");
-        }
+        nsplit_check_shape(c, ci);
         if (!w3 || !w0 || !w2) throw std::invalid_argument("dcb_nsplit: missing operand");
-        dcvc::DcbNsplitDesc d;
-        d.t2 = H(t2); d.ldt = ldt; d.x = H(x); d.ldx = ldx;
-        d.wmain = packed_for(w3, w0, w2, c, ci, false, S(stream));
-        d.wnext = w1n != nullptr ? packed_for(w1n, nullptr, nullptr, c, ci, true, S(stream)) : nullptr;
-        d.b3 = H(b3); d.b0 = H(b0); d.b2 = H(b2); d.b1n = H(b1n); d.q = H(q); d.q2 = H(q2);
-        d.t1n = H(t1n); d.ldt1 = ldt1; d.y = H(y); d.ldy = ldy;
-        d.pixels = pixels; d.c = c; d.ci = ci; d.shortcut = shortcut != 0;
-        dcvc::dcb_nsplit(d, S(stream));
+        hipStream_t st = S(stream);
+        void* wmain = nullptr;
+        void* wnext = nullptr;
+        dcvc::hip_check(hipMallocAsync(&wmain, dcvc::dcb_nsplit_main_halves(c, ci) * 2, st), "hipMallocAsync(packed weights)");
+        dcvc::dcb_nsplit_pack_main(H(w3), H(w0), H(w2), c, ci, static_cast<dcvc::half_t*>(wmain), st);
+        if (w1n != nullptr) {
+            dcvc::hip_check(hipMallocAsync(&wnext, dcvc::dcb_nsplit_dc0_halves(c, ci) * 2, st), "hipMallocAsync(packed weights)");
+            dcvc::dcb_nsplit_pack_dc0(H(w1n), c, ci, static_cast<dcvc::half_t*>(wnext), st);
+        }
+        try {
+            nsplit_launch(static_cast<dcvc::half_t*>(wmain), static_cast<dcvc::half_t*>(wnext), t2, ldt, x, ldx, b3, b0, b2, q, q2, b1n,
+                          t1n, ldt1, y, ldy, pixels, c, ci, shortcut, st);
+        } catch (...) {
+            (void)hipFreeAsync(wmain, st);
+            if (wnext) (void)hipFreeAsync(wnext, st);
+            throw;
+        }
+        dcvc::hip_check(hipFreeAsync(wmain, st), "hipFreeAsync(packed weights)");
+        if (wnext) dcvc::hip_check(hipFreeAsync(wnext, st), "hipFreeAsync(packed weights)");
+    });
+}
+
+int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const void* w1n, int c, int ci, void* stream, void** handle)
+{
+    return dcvc::guarded([&] {
+        dcvc::kernels_init();
+        nsplit_check_shape(c, ci);
+        if (!w3 || !w0 || !w2 || !handle) throw std::invalid_argument("dcb_nsplit_pack: missing operand");
+        auto pk = std::make_unique<NsplitPacked>();
+        pk->c = c; pk->ci = ci;
+        dcvc::hip_check(hipGetDevice(&pk->device), "hipGetDevice");
+        void* m = nullptr;
+        dcvc::hip_check(hipMalloc(&m, dcvc::dcb_nsplit_main_halves(c, ci) * 2), "hipMalloc(packed weights)");
+        pk->main = static_cast<dcvc::half_t*>(m);
+        dcvc::dcb_nsplit_pack_main(H(w3), H(w0), H(w2), c, ci, pk->main, S(stream));
+        if (w1n != nullptr) {
+            void* n = nullptr;
+            if (hipMalloc(&n, dcvc::dcb_nsplit_dc0_halves(c, ci) * 2) != hipSuccess) {
+                (void)hipFree(m);
+                throw std::runtime_error("hipMalloc(packed weights)");
+            }
+            pk->next = static_cast<dcvc::half_t*>(n);
+            dcvc::dcb_nsplit_pack_dc0(H(w1n), c, ci, pk->next, S(stream));
+        }
+        *handle = pk.release();
+    });
+}
+
+int dcvc_dcb_nsplit_free(void* handle)
+{
+    return dcvc::guarded([&] {
+        if (handle == nullptr) return;
+        std::unique_ptr<NsplitPacked> pk(static_cast<NsplitPacked*>(handle));
+        dcvc::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");      // launches that still read the packed copies
+        (void)hipFree(pk->main);
+        if (pk->next) (void)hipFree(pk->next);
+    });
+}
+
+int dcvc_dcb_nsplit_packed(const void* handle, const void* t2, int ldt, const void* x, int ldx, const void* b3, const void* b0,
+                           const void* b2, const void* q, const void* q2, const void* b1n, void* t1n, int ldt1,
+                           void* y, int ldy, int pixels, int shortcut, int with_next, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::kernels_init();
+        if (handle == nullptr) throw std::invalid_argument("dcb_nsplit_packed: null handle");
+        const NsplitPacked* pk = static_cast<const NsplitPacked*>(handle);
+        int dev = 0;
+        dcvc::hip_check(hipGetDevice(&dev), "hipGetDevice");
+        if (dev != pk->device) throw std::invalid_argument("dcb_nsplit_packed: the handle was packed on another device");
+        if (with_next && pk->next == nullptr) throw std::invalid_argument("dcb_nsplit_packed: packed without the next block's dc.0");
+        nsplit_launch(pk->main, with_next ? pk->next : nullptr, t2, ldt, x, ldx, b3, b0, b2, q, q2, b1n, t1n, ldt1, y, ldy, pixels,
+                      pk->c, pk->ci, shortcut, S(stream));
     });
 }
 

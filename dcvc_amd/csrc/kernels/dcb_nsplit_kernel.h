@@ -47,6 +47,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <type_traits>
 
 namespace dcvc {
@@ -693,18 +694,28 @@ void launch(const NsParams& p, hipStream_t stream)
     auto kern = dcb_nsplit_kernel<C, CI, PXT, NEXT>;
     constexpr int smem = smem_bytes<C, CI, PXT>();
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static std::once_flag once;
-    std::call_once(once, [&] {
+    // per device (advisor, round 3: a process-wide once-flag left a second device without the LDS attribute and with the
+    // first device's CU count): the attribute is set, and the CU count read, once per device id
+    constexpr int MAX_DEVICES = 64;
+    static std::once_flag once[MAX_DEVICES];
+    static int cu_count[MAX_DEVICES];
+    int dev = 0;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    if (dev < 0 || dev >= MAX_DEVICES) throw std::runtime_error("dcb_nsplit: device id out of range");
+    std::call_once(once[dev], [&] {
+        hipDeviceProp_t prop;
+        hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+            throw std::runtime_error(std::string("dcb_nsplit needs gfx950 (160 KB LDS, permlane32_swap); device is ") + prop.gcnArchName);
+        }
         hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
                   "hipFuncSetAttribute(dcb_nsplit)");
+        int n = 0;
+        hip_check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
+        cu_count[dev] = n > 0 ? n : 256;
     });
     // persistent workgroups: one per CU (up to 160 KB of LDS each), tiles dealt round-robin
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        hip_check(hipGetDevice(&dev), "hipGetDevice");
-        hip_check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
-        return n > 0 ? n : 256;
-    }();
+    const int cus = cu_count[dev];
     const int tiles = (p.M + 32 * PXT - 1) / (32 * PXT);
     const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;

@@ -4,6 +4,9 @@
 #include "rans_coder.h"
 
 #include <chrono>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstdlib>
 
 #include <algorithm>
@@ -110,15 +113,9 @@ inline uint32_t dec_bits(DecState& s)
     return val;
 }
 
-inline int8_t dec_symbol(DecState& s, const CdfTable& t, int cdf_idx)
+// Everything of a symbol behind the CDF search: state update, byte renormalisation, escape groups.
+inline int8_t dec_finish(DecState& s, const uint32_t* cdf, int v, uint32_t cum, int32_t max_value)
 {
-    const uint32_t* cdf = t.cdf.data() + static_cast<size_t>(cdf_idx) * t.stride;
-    const int32_t max_value = t.max_value[cdf_idx];
-    const uint32_t cum = s.r & kProbMask;
-    int v = t.first.empty() ? 0 : t.first[static_cast<size_t>(cdf_idx) * 256 + (cum >> 8)];
-    while (cdf[v + 1] <= cum) {
-        ++v;
-    }
     const uint32_t start = cdf[v];
     const uint32_t freq = cdf[v + 1] - start;
     uint32_t r = freq * (s.r >> kRansProbBits) + cum - start;
@@ -156,6 +153,76 @@ inline int8_t dec_symbol(DecState& s, const CdfTable& t, int cdf_idx)
     const int32_t mag = (value + 1) >> 1;
     return static_cast<int8_t>((value & 1) ? mag : -mag);
 }
+
+// Portable search: start at the value whose interval holds (cum & ~255), scan upwards.
+inline int8_t dec_symbol(DecState& s, const CdfTable& t, int cdf_idx)
+{
+    const uint32_t* cdf = t.cdf.data() + static_cast<size_t>(cdf_idx) * t.stride;
+    const uint32_t cum = s.r & kProbMask;
+    int v = t.first.empty() ? 0 : t.first[static_cast<size_t>(cdf_idx) * 256 + (cum >> 8)];
+    while (cdf[v + 1] <= cum) {
+        ++v;
+    }
+    return dec_finish(s, cdf, v, cum, t.max_value[cdf_idx]);
+}
+
+#if defined(__x86_64__)
+// AVX-512 search (round 4): a CDF row of the reference's tables has at most 19 entries, so the whole
+// row sits in ONE 512-bit register as 32 x u16 (`edge`: cdf[j] - 1 for j = 1 .. size - 1, 0xFFFF beyond; the terminal
+// 2^16 becomes 0xFFFF, which no 16-bit cum exceeds): value = number of j >= 1 with cdf[j] <= cum = popcount of ONE
+// unsigned compare - no scan loop and, above all, no data-dependent loop exit to mispredict (the exit of the scan above
+// is close to a coin flip per symbol on spread distributions). The row's address depends on the index stream only, so
+// its load runs ahead of the serial state chain. Same arithmetic, same bytes: tests/test_rans.py runs both paths.
+#define DCVC_RANS_AVX512 1
+__attribute__((target("avx512f,avx512bw,popcnt"))) inline int search_avx512(const uint16_t* edge_row, uint32_t cum)
+{
+    const __m512i row = _mm512_load_si512(reinterpret_cast<const void*>(edge_row));
+    const __mmask32 le = _mm512_cmplt_epu16_mask(row, _mm512_set1_epi16(static_cast<short>(cum)));
+    return static_cast<int>(_mm_popcnt_u32(static_cast<unsigned>(le)));
+}
+
+__attribute__((target("avx512f,avx512bw,popcnt")))
+void decode_y_avx512(DecState& st, const CdfTable& t, const uint8_t* indexes, int b, int len, int8_t* out)
+{
+    const uint32_t* const cdf0 = t.cdf.data();
+    const uint16_t* const edge = t.edge.data();
+    const size_t stride = static_cast<size_t>(t.stride);
+    for (int k = b; k < b + len; ++k) {
+        const int idx = indexes[k];
+        const uint32_t cum = st.r & kProbMask;
+        const int v = search_avx512(edge + static_cast<size_t>(idx) * CdfTable::kEdgeRow, cum);
+        out[k] = dec_finish(st, cdf0 + idx * stride, v, cum, t.max_value[idx]);
+    }
+}
+
+__attribute__((target("avx512f,avx512bw,popcnt")))
+void decode_z_avx512(DecState& st, const CdfTable& t, int cdf_offset, int ch, int b, int len, int8_t* out)
+{
+    const uint32_t* const cdf0 = t.cdf.data();
+    const uint16_t* const edge = t.edge.data();
+    const size_t stride = static_cast<size_t>(t.stride);
+    for (int k = b; k < b + len; ++k) {
+        const int idx = (k % ch) + cdf_offset;
+        const uint32_t cum = st.r & kProbMask;
+        const int v = search_avx512(edge + static_cast<size_t>(idx) * CdfTable::kEdgeRow, cum);
+        out[k] = dec_finish(st, cdf0 + idx * stride, v, cum, t.max_value[idx]);
+    }
+}
+
+bool cpu_has_avx512bw()
+{
+    static const bool have = [] {
+        if (const char* e = getenv("DCVC_RANS_AVX512")) {
+            if (atoi(e) == 0) return false;             // A/B switch and the portable path's test hook
+        }
+        __builtin_cpu_init();
+        return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("popcnt");
+    }();
+    return have;
+}
+#else
+bool cpu_has_avx512bw() { return false; }
+#endif
 
 inline void slice_of(int count, int n, int i, int& begin, int& len)
 {
@@ -228,6 +295,18 @@ void CdfTable::load(const int32_t* cdfs, int num_cdf, int row_stride, const int3
                 }
                 rcp[e] = static_cast<uint32_t>(((1ull << (shift + 31)) + f - 1) / f);
                 rcp_shift[e] = static_cast<uint8_t>(shift - 1);
+            }
+        }
+    }
+    // AVX-512 search rows (see search_avx512): 32 x u16 per CDF, 64-byte aligned
+    edge.clear();
+    if (stride <= kEdgeRow + 1 && kRansProbBits == 16 && cpu_has_avx512bw()) {
+        edge.assign(static_cast<size_t>(num) * kEdgeRow, 0xFFFFu);
+        for (int i = 0; i < num; ++i) {
+            const uint32_t* row = cdf.data() + static_cast<size_t>(i) * stride;
+            const int size = cdf_sizes[i];                  // entries of the row: 0, ..., 2^16
+            for (int j = 1; j < size && j <= kEdgeRow; ++j) {
+                edge[static_cast<size_t>(i) * kEdgeRow + (j - 1)] = static_cast<uint16_t>(row[j] - 1u);
             }
         }
     }
@@ -612,6 +691,11 @@ void RansDecoder::decode_y(const uint8_t* indexes, int count, int8_t* out)
         Sub& sub = m_sub[i];
         DecState st{ sub.state, sub.ptr, sub.end };
         const CdfTable& t = m_tab[1];
+#ifdef DCVC_RANS_AVX512
+        if (!t.edge.empty()) {
+            decode_y_avx512(st, t, indexes, b, len, out);
+        } else
+#endif
         for (int k = b; k < b + len; ++k) {
             out[k] = dec_symbol(st, t, indexes[k]);
         }
@@ -629,6 +713,11 @@ void RansDecoder::decode_z(int count, int cdf_offset, int ch, int8_t* out)
         Sub& sub = m_sub[i];
         DecState st{ sub.state, sub.ptr, sub.end };
         const CdfTable& t = m_tab[0];
+#ifdef DCVC_RANS_AVX512
+        if (!t.edge.empty()) {
+            decode_z_avx512(st, t, cdf_offset, ch, b, len, out);
+        } else
+#endif
         for (int k = b; k < b + len; ++k) {
             out[k] = dec_symbol(st, t, (k % ch) + cdf_offset);
         }

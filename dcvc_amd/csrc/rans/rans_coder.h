@@ -17,6 +17,8 @@
 #include <exception>
 #include <functional>
 #include <mutex>
+#include <cstdlib>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -42,6 +44,22 @@ struct CdfTable {
     // 128 Gaussian tables = 32 KB, L1-resident; the per-channel z tables code ~1 % of the symbols)
     static constexpr int kLutRows = 256;
     std::vector<uint8_t> first;
+    // AVX-512 search rows (hosts with AVX-512BW): edge[i * kEdgeRow + j - 1] = cdf[i][j] - 1, 0xFFFF beyond the row
+    static constexpr int kEdgeRow = 32;
+    template <class T> struct Aligned64 {             // rows must not straddle cache lines; copies of a table stay aligned
+        using value_type = T;
+        Aligned64() = default;
+        template <class U> Aligned64(const Aligned64<U>&) {}
+        T* allocate(size_t n) {
+            void* p = std::aligned_alloc(64, (n * sizeof(T) + 63) / 64 * 64);
+            if (!p) throw std::bad_alloc();
+            return static_cast<T*>(p);
+        }
+        void deallocate(T* p, size_t) { std::free(p); }
+        template <class U> bool operator==(const Aligned64<U>&) const { return true; }
+        template <class U> bool operator!=(const Aligned64<U>&) const { return false; }
+    };
+    std::vector<uint16_t, Aligned64<uint16_t>> edge;      // empty = portable search
     void load(const int32_t* cdfs, int num_cdf, int row_stride, const int32_t* cdf_sizes);
 };
 

@@ -84,7 +84,8 @@ int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w
 
 /* The same operator (plus the inner width ci = cdc = cffn) through the N-split kernel (round 3: activations in LDS, every wave owns a quarter
  * of the output channels and streams its weight fragments from a packed copy of w3 | w0 | w2 [| w1n] that this entry point
- * builds on first use and caches per weight pointer - the codecs pack once at set_param time).
+ * builds on EVERY call in stream-ordered temporaries - the codecs pack once at set_param time; callers that launch many
+ * times use the handle form below).
  * (c, ci) in {(256, 256), (384, 384), (512, 512), (768, 768)} - full-width blocks - and {(512, 256), (256, 128)}: the
  * half-width `dcb2` blocks of the inter models (layers.py:128-159; w3 [c][ci], w0 [4 ci][c], w2 [c][ci], w1n [ci][c]).
  * Bit-identical to dcvc_dcb_core / dcvc_dcb_tail and to the separate launches. */
@@ -92,6 +93,16 @@ int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void*
                     const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
                     const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
                     int pixels, int c, int ci, int shortcut, void* stream);
+/* Handle form: pack w3 | w0 | w2 (and w1n, or NULL) once - the packed copies are a snapshot of the weights at pack time -,
+ * launch any number of times, free (synchronises the device). with_next != 0 runs the next block's dc.0 inside the launch
+ * (the handle must have been packed with w1n). No reference counterpart: the reference's CUTLASS kernels read the
+ * row-major matrices directly. */
+int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const void* w1n, int c, int ci, void* stream,
+                         void** handle);
+int dcvc_dcb_nsplit_packed(const void* handle, const void* t2, int ldt, const void* x, int ldx, const void* b3,
+                           const void* b0, const void* b2, const void* q, const void* q2, const void* b1n,
+                           void* t1n, int ldt1, void* y, int ldy, int pixels, int shortcut, int with_next, void* stream);
+int dcvc_dcb_nsplit_free(void* handle);
 
 /* DepthConvBlockProxy::forward behind dc.0 (layers_proxy.cpp:79-98: d3x3, conv1x1_bias_shortcut,
  * conv1x1_bias_wsilu_chunk_add, conv1x1_bias_shortcut[2][_with_quant]) in one launch for the

@@ -46,6 +46,10 @@ class Ops:
                                              ci, ci, ci, vp])
         self.dcb_nsplit = _f("dcvc_dcb_nsplit", [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci,
                                                  ci, ci, ci, ci, vp])
+        self.dcb_nsplit_pack = _f("dcvc_dcb_nsplit_pack", [vp, vp, vp, vp, ci, ci, vp, ctypes.POINTER(vp)])
+        self.dcb_nsplit_packed = _f("dcvc_dcb_nsplit_packed", [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci,
+                                                               ci, ci, ci, vp])
+        self.dcb_nsplit_free = _f("dcvc_dcb_nsplit_free", [vp])
         self.scale_clamped = _f("dcvc_scale_clamped", [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp])
 
 

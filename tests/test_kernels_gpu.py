@@ -635,3 +635,60 @@ def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, n
     if C == 384:
         y2, t12 = run(ops.dcb_core)
         assert torch.equal(y2, ybuf) and torch.equal(t12, t1)
+
+
+def test_dcb_nsplit_reads_the_weights_of_the_call(ops):
+    """dcvc_dcb_nsplit packs the weights it is GIVEN, on every call: rewriting them in place between two calls (same
+    pointers - round 3's pointer-keyed cache returned the first call's copy, advisor finding) changes the result
+    accordingly; the handle form keeps the snapshot taken at pack time until it is packed again."""
+    import ctypes
+    from gpu_util import call, ptr, stream
+    dev, C, CI, P = "cuda", 256, 128, 300
+    x = _rand((P, C), 1.0, 501).to(dev)
+    t2 = _rand((P, CI), 1.0, 502).to(dev)
+    ws = [(_rand(shape, 1.0, 503 + i) / shape[1] ** 0.5).half().to(dev) for i, shape in enumerate(((C, CI), (4 * CI, C), (C, CI), (CI, C)))]
+    bs = [_rand((n,), 0.3, 510 + i).to(dev) for i, n in enumerate((C, 4 * CI, C, CI))]
+
+    def direct():
+        y = torch.zeros((P, C), dtype=torch.half, device=dev)
+        t1 = torch.zeros((P, CI), dtype=torch.half, device=dev)
+        call(ops.dcb_nsplit, ptr(t2), CI, ptr(x), C, ptr(ws[0]), ptr(bs[0]), ptr(ws[1]), ptr(bs[1]), ptr(ws[2]), ptr(bs[2]), None, None,
+             ptr(ws[3]), ptr(bs[3]), ptr(t1), CI, ptr(y), C, P, C, CI, 0, stream())
+        torch.cuda.synchronize()
+        return y, t1
+
+    def packed(handle):
+        y = torch.zeros((P, C), dtype=torch.half, device=dev)
+        t1 = torch.zeros((P, CI), dtype=torch.half, device=dev)
+        call(ops.dcb_nsplit_packed, handle, ptr(t2), CI, ptr(x), C, ptr(bs[0]), ptr(bs[1]), ptr(bs[2]), None, None, ptr(bs[3]),
+             ptr(t1), CI, ptr(y), C, P, 0, 1, stream())
+        torch.cuda.synchronize()
+        return y, t1
+
+    h = ctypes.c_void_p()
+    call(ops.dcb_nsplit_pack, ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(ws[3]), C, CI, stream(), ctypes.byref(h))
+    y_a, t_a = direct()
+    y_h, t_h = packed(h)
+    assert torch.equal(y_a, y_h) and torch.equal(t_a, t_h)
+    for i, w in enumerate(ws):                   # new values at the SAME addresses
+        w.copy_((_rand(tuple(w.shape), 1.0, 520 + i) / w.shape[1] ** 0.5).half())
+    torch.cuda.synchronize()
+    y_b, t_b = direct()
+    assert not torch.equal(y_a, y_b) and not torch.equal(t_a, t_b), "the second call still used the first call's weights"
+    y_h2, t_h2 = packed(h)
+    assert torch.equal(y_h2, y_a) and torch.equal(t_h2, t_a), "a handle is a snapshot"
+    h2 = ctypes.c_void_p()
+    call(ops.dcb_nsplit_pack, ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(ws[3]), C, CI, stream(), ctypes.byref(h2))
+    y_h3, t_h3 = packed(h2)
+    assert torch.equal(y_h3, y_b) and torch.equal(t_h3, t_b)
+    # the launch sequence on the new weights agrees (the block's semantics, not just "something changed")
+    y1 = torch.zeros((P, C), dtype=torch.half, device=dev)
+    t = torch.zeros((P, CI), dtype=torch.half, device=dev)
+    want = torch.zeros((P, C), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(t2), CI, ptr(ws[0]), ptr(bs[0]), ptr(x), C, None, 0, None, None, ptr(y1), C, P, CI, C, 0, stream())
+    call(ops.conv1x1, ptr(y1), C, ptr(ws[1]), ptr(bs[1]), None, 0, None, 0, None, None, ptr(t), CI, P, C, 4 * CI, 3, stream())
+    call(ops.conv1x1, ptr(t), CI, ptr(ws[2]), ptr(bs[2]), ptr(y1), C, None, 0, None, None, ptr(want), C, P, CI, C, 0, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(want, y_b)
+    call(ops.dcb_nsplit_free, h)
+    call(ops.dcb_nsplit_free, h2)

@@ -29,6 +29,9 @@ typedef int (*core_fn)(const void*, int, const void*, int, const void*, const vo
                        const void*, const void*, const void*, const void*, const void*, void*, int, void*, int, int, int, int, void*);
 typedef int (*ns_fn)(const void*, int, const void*, int, const void*, const void*, const void*, const void*, const void*,
                      const void*, const void*, const void*, const void*, const void*, void*, int, void*, int, int, int, int, int, void*);
+typedef int (*nspack_fn)(const void*, const void*, const void*, const void*, int, int, void*, void**);
+typedef int (*nspacked_fn)(const void*, const void*, int, const void*, int, const void*, const void*, const void*, const void*, const void*,
+                           const void*, void*, int, void*, int, int, int, int, void*);
 typedef int (*conv_fn)(const void*, int, const void*, const void*, const void*, int, const void*, int, const void*, const void*,
                        void*, int, int, int, int, int, void*);
 typedef int (*dw_fn)(const void*, int, const void*, void*, int, int, int, int, void*);
@@ -40,6 +43,9 @@ struct Lib {
     void* h = nullptr;
     core_fn core = nullptr;
     ns_fn ns = nullptr;            // dcvc_dcb_nsplit (+ the inner width), round 3
+    nspack_fn ns_pack = nullptr;   // round 4: dcvc_dcb_nsplit packs per call; the handle form is what gets timed
+    nspacked_fn ns_packed = nullptr;
+    void* ns_handle = nullptr;
     conv_fn conv = nullptr;
     dw_fn dw = nullptr;
     tl_fn tl = nullptr;
@@ -94,6 +100,8 @@ int main(int argc, char** argv)
         l.core = reinterpret_cast<core_fn>(dlsym(l.h, "dcvc_dcb_core"));
         l.conv = reinterpret_cast<conv_fn>(dlsym(l.h, "dcvc_conv1x1"));
         l.ns = reinterpret_cast<ns_fn>(dlsym(l.h, "dcvc_dcb_nsplit"));
+        l.ns_pack = reinterpret_cast<nspack_fn>(dlsym(l.h, "dcvc_dcb_nsplit_pack"));
+        l.ns_packed = reinterpret_cast<nspacked_fn>(dlsym(l.h, "dcvc_dcb_nsplit_packed"));
         l.dw = reinterpret_cast<dw_fn>(dlsym(l.h, "dcvc_dwconv3x3"));
         l.tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_core_timeline_buffer"));
         l.ns_tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_nsplit_timeline_buffer"));
@@ -127,6 +135,12 @@ int main(int argc, char** argv)
                       y, C, P, C, 0, st), "dcb_core");
     };
     auto nsplit = [&](Lib& l, bool next) {
+        if (l.ns_pack && l.ns_packed) {
+            if (!l.ns_handle) chk(l, l.ns_pack(w3, w0, w2, w1, C, CI, st, &l.ns_handle), "dcb_nsplit_pack");
+            chk(l, l.ns_packed(l.ns_handle, t2, CI, x, C, b3, b0, b2, nullptr, nullptr, next ? b1 : nullptr, next ? t1 : nullptr, CI,
+                               y, C, P, 0, next ? 1 : 0, st), "dcb_nsplit_packed");
+            return;
+        }
         chk(l, l.ns(t2, CI, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, next ? w1 : nullptr, next ? b1 : nullptr, next ? t1 : nullptr, CI,
                     y, C, P, C, CI, 0, st), "dcb_nsplit");
     };
