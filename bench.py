@@ -497,6 +497,8 @@ def main():
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if os.environ.get("DCVC_BENCH_ONE_DEVICE"):
+        local_rank = 0           # tests/test_bench_gpu.py: the whole N-rank launch path on a 1-GPU box (with the gloo backend)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # as the reference harness (test_video.py:423-425): the process works on a non-default stream

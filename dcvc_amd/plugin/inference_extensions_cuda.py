@@ -255,13 +255,24 @@ class _DMCHTProxy(_Proxy):
                                      int(width), int(entropy_coder_parallel),
                                      1 if reset_feature_memory else 0,
                                      ctypes.c_void_p(self._x_hat.data_ptr()), _stream_ptr()))
-        return [self._x_hat[i:i + 1] for i in range(self.FRAMES)]
+        return self._pictures(self._recon_mask)
+
+    _recon_mask = 0xFF
+
+    def _pictures(self, mask):
+        """the 8 entries of a decompress() / run_recon_heads() result: pictures whose head did not run are None, not a
+        view of a buffer nobody wrote (advisor, round 3: a plain decompress() behind a fan-out returned stale tensors)"""
+        return [self._x_hat[i:i + 1] if (mask >> i) & 1 else None for i in range(self.FRAMES)]
 
     # ---- reconstruction-head fan-out over several GPUs (not part of the reference surface; SURVEY 8e iii)
     def set_recon_mask(self, mask):
         """decompress() runs only the heads of the pictures in bit mask `mask` (the other entries of the
         returned list are then not written)."""
         _lib.check(_HT["set_recon_mask"](self._h, int(mask) & 0xFF))
+        self._recon_mask = int(mask) & 0xFF
+
+    def recon_mask(self):
+        return self._recon_mask
 
     def export_feature(self):
         """feature_p of the last decompress() as a dense fp16 device tensor [P8, 512]"""
@@ -285,7 +296,7 @@ class _DMCHTProxy(_Proxy):
             self._x_hat = torch.empty((self.FRAMES, 3, h16, w16), dtype=torch.float16, device=device).contiguous(
                 memory_format=torch.channels_last)
         _lib.check(_HT["run_recon_heads"](self._h, int(mask) & 0xFF, ctypes.c_void_p(self._x_hat.data_ptr()), _stream_ptr()))
-        return [self._x_hat[i:i + 1] for i in range(self.FRAMES)]
+        return self._pictures(int(mask) & 0xFF)
 
 
 _DMCHTProxy.export_state = _export_state

@@ -112,6 +112,12 @@ def head_mask(rank, world):
     return sum(1 << i for i in range(8) if head_owner(i, world) == rank)
 
 
+def _to_wire(t, dist):
+    """a tensor as the backend can carry it: device tensors over RCCL, host tensors over gloo (which has no
+    point-to-point for device memory) - the latter also on a GPU box (bench.py's gloo mode, tests)"""
+    return t if dist.get_backend() == "nccl" or not t.is_cuda else t.cpu()
+
+
 def decompress_fanout(proxy, bit_stream, qp, height, width, ec_parallel, reset, dist, src=0):
     """One chunk of an HT stream decoded over all ranks of `dist`. `bit_stream` etc. are needed on
     rank `src` only. Returns this rank's {picture index: x_hat tensor}.
@@ -119,24 +125,39 @@ def decompress_fanout(proxy, bit_stream, qp, height, width, ec_parallel, reset, 
     Rank `src` decodes WITHOUT its reconstruction heads (recon mask 0: entropy decoding, priors, decoder),
     exports feature_p, starts the broadcast asynchronously (RCCL runs it on its own stream) and only then
     runs its own heads - so the transfer and the other ranks' heads overlap the owner's heads instead of
-    waiting for them. The recon mask of the owner's proxy stays 0 afterwards (switching it re-captures the
-    decode graphs): call restore_heads(proxy) before using that proxy for a plain decompress() again."""
+    waiting for them. The recon mask of the owner's proxy STAYS 0 afterwards (switching it re-captures the
+    decode graphs, so a stream of fan-out calls must not flip it per chunk): a plain decompress() of that proxy
+    then returns None for every picture until restore_heads(proxy) - or use the fanout_heads() context manager."""
     rank, world = dist.get_rank(), dist.get_world_size()
     if world > 8:
         raise ValueError("recon-head fan-out: a chunk has 8 pictures, at most 8 ranks can take part")
+    if not 0 <= src < world:
+        raise ValueError("bad src rank")
     mask = head_mask((rank - src) % world, world)
     if rank == src:
-        proxy.set_recon_mask(0)
+        if getattr(proxy, "recon_mask", lambda: None)() != 0:
+            proxy.set_recon_mask(0)
         proxy.decompress(bit_stream, qp, height, width, ec_parallel, reset)
-        feature = proxy.export_feature()
+        feature = _to_wire(proxy.export_feature(), dist)
         work = dist.broadcast(feature, src, async_op=True) if world > 1 else None
         out = proxy.run_recon_heads(mask, height, width)
         if work is not None:
             work.wait()                  # `feature` must outlive the transfer; the heads above did not wait for it
     else:
         h8, w8 = (height + 15) // 16 * 2, (width + 15) // 16 * 2
-        feature = torch.empty(h8 * w8 * 512, dtype=torch.float16, device=_device_for(dist))
+        # one receive buffer per proxy and picture size (round 3 allocated 33 MB per chunk)
+        key = (h8 * w8 * 512, str(_device_for(dist)))
+        cache = getattr(proxy, "_fanout_rx", None)
+        if cache is None or cache[0] != key:
+            cache = (key, torch.empty(key[0], dtype=torch.float16, device=_device_for(dist)))
+            try:
+                proxy._fanout_rx = cache
+            except AttributeError:
+                pass
+        feature = cache[1]
         dist.broadcast(feature, src)
+        if not feature.is_cuda and torch.cuda.is_available():
+            feature = feature.cuda()             # gloo on a GPU box: the transfer went through host memory
         proxy.import_feature(feature, height, width)
         out = proxy.run_recon_heads(mask, height, width)
     return {i: out[i] for i in range(8) if mask >> i & 1}
@@ -147,34 +168,58 @@ def restore_heads(proxy):
     proxy.set_recon_mask(0xFF)
 
 
+class fanout_heads:
+    """`with fanout_heads(proxy): ... decompress_fanout(proxy, ...) ...` - the owner's recon mask is back at all
+    8 heads when the block ends (one graph re-capture at each end, none per chunk)."""
+
+    def __init__(self, proxy):
+        self.proxy = proxy
+
+    def __enter__(self):
+        return self.proxy
+
+    def __exit__(self, *exc):
+        restore_heads(self.proxy)
+        return False
+
+
 def gather_pictures(mine, dist, dst=0, src=0, shape=None, dtype=torch.float16, device=None):
     """{picture: [1, 3, H, W] tensor} of every rank -> on rank `dst` the 8 pictures in display order (None
     elsewhere). Point-to-point: every picture travels once, from the rank that reconstructed it
-    (head_owner, relative to the fan-out's `src`) to `dst`. `shape` / `dtype` / `device` describe a picture
-    for a `dst` that owns none itself; by default they are taken from one of its own."""
+    (head_owner, relative to the fan-out's `src` - pass the SAME src as to decompress_fanout: checked) to `dst`.
+    `shape` / `dtype` / `device` describe a picture for a `dst` that owns none itself; by default they are taken from
+    one of its own."""
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return [mine[i] for i in range(8)]
+    if rank == dst and shape is None and not mine:
+        raise ValueError("gather_pictures: rank %d owns no picture - pass shape / dtype / device" % rank)
+    want = {i for i in range(8) if (head_owner(i, world) + src) % world == rank}
+    if set(mine) != want:
+        raise ValueError("gather_pictures: rank %d holds pictures %s but owns %s for src=%d - the fan-out ran with another src"
+                         % (rank, sorted(mine), sorted(want), src))
     if rank != dst:
-        reqs = [dist.isend(mine[i].contiguous(), dst) for i in sorted(mine)]
+        reqs = [dist.isend(_to_wire(mine[i].contiguous(), dist), dst) for i in sorted(mine)]
         for r in reqs:
             r.wait()
         return None
     if shape is None:
-        if not mine:
-            raise ValueError("gather_pictures: rank %d owns no picture - pass shape / dtype / device" % rank)
         any_t = next(iter(mine.values()))
         shape, dtype, device = tuple(any_t.shape), any_t.dtype, any_t.device
     out, reqs = [None] * 8, []
+    wire_dev = _device_for(dist)
     for i in range(8):
         owner = (head_owner(i, world) + src) % world
         if owner == dst:
             out[i] = mine[i]
         else:
-            out[i] = torch.empty(shape, dtype=dtype, device=device if device is not None else _device_for(dist))
+            out[i] = torch.empty(shape, dtype=dtype, device=wire_dev if dist.get_backend() != "nccl" else
+                                 (device if device is not None else wire_dev))
             reqs.append(dist.irecv(out[i], owner))
     for r in reqs:
         r.wait()
+    if device is not None:
+        out = [t if t.device == torch.device(device) else t.to(device) for t in out]
     return out
 
 
