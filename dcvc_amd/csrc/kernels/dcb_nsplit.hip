@@ -1,5 +1,6 @@
 // Host side of the N-split DepthConvBlock kernel (dcb_nsplit_kernel.h): weight packing, shape dispatch.
 #include "dcb_nsplit_kernel.h"
+#include "dcb_nsplit8_kernel.h"
 
 namespace dcvc {
 
@@ -21,14 +22,18 @@ __global__ void pack_main_kernel(const half_t* w3, const half_t* w0, const half_
     const int wave = static_cast<int>((u >> 6) / F_MAIN);
     const half_t* w;
     int n0, ks, K;
+    // (NS_CHMAJOR: dc.3 / ffn.2 / dc.0 consume their fragments channel tile by channel tile - tile j's KS slices, then
+    // tile j + 1's -, otherwise k-slice by k-slice over all tiles; ffn.0 always k-slice by k-slice within a pass)
     if (f < F_DC3) {                                  // dc.3 [C][CI]
-        ks = f / MT_C; n0 = 32 * (wave * MT_C + f % MT_C); w = w3; K = CI;
+        if (CHMAJOR) { ks = f % KS_I; n0 = 32 * (wave * MT_C + f / KS_I); } else { ks = f / MT_C; n0 = 32 * (wave * MT_C + f % MT_C); }
+        w = w3; K = CI;
     } else if (f < F_DC3 + F_FFN0) {                  // ffn.0 [4 CI][C]: the wave's CI channels in passes of TP tiles
         const int g = f - F_DC3, pass = g / (TP * KS_C), r = g % (TP * KS_C);
         ks = r / TP; n0 = wave * CI + pass * 32 * TP + 32 * (r % TP); w = w0; K = C;
     } else {                                          // ffn.2 [C][CI]
         const int g = f - F_DC3 - F_FFN0;
-        ks = g / MT_C; n0 = 32 * (wave * MT_C + g % MT_C); w = w2; K = CI;
+        if (CHMAJOR) { ks = g % KS_I; n0 = 32 * (wave * MT_C + g / KS_I); } else { ks = g / MT_C; n0 = 32 * (wave * MT_C + g % MT_C); }
+        w = w2; K = CI;
     }
     out[u] = *reinterpret_cast<const half8*>(w + static_cast<size_t>(n0 + (lane & 31)) * K + 16 * ks + 8 * (lane >> 5));
 }
@@ -41,13 +46,59 @@ __global__ void pack_dc0_kernel(const half_t* w1, int C, int CI, half8* out)    
     const int lane = static_cast<int>(u & 63);
     const int f = static_cast<int>((u >> 6) % F);
     const int wave = static_cast<int>((u >> 6) / F);
-    const int ks = f / MT_I, n0 = 32 * (wave * MT_I + f % MT_I);
+    const int ks = CHMAJOR ? f % KS_C : f / MT_I, n0 = 32 * (wave * MT_I + (CHMAJOR ? f / KS_C : f % MT_I));
+    out[u] = *reinterpret_cast<const half8*>(w1 + static_cast<size_t>(n0 + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5));
+}
+
+// ---- the 8-wave kernel's streams (dcb_nsplit8_kernel.h): waves 0 .. 3, then 4 .. 7; waves w and w + 4 share the tiles
+// [simd QC, (simd + 1) QC) of a C-wide layer (w the first HI, w + 4 the remaining LO); ffn.0: N0 tiles per wave in passes of 2
+__global__ void pack_main8_kernel(const half_t* w3, const half_t* w0, const half_t* w2, int C, int CI, half8* out)
+{
+    const int KS_C = C / 16, KS_I = CI / 16, QC = C / 128, HI_C = (QC + 1) / 2, LO_C = QC / 2, N0 = CI / 64, TP = 2;
+    const int F_FFN0 = N0 * KS_C, FM_HI = 2 * HI_C * KS_I + F_FFN0, FM_LO = 2 * LO_C * KS_I + F_FFN0;
+    const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (u >= 4LL * (FM_HI + FM_LO) * 64) return;
+    const int lane = static_cast<int>(u & 63);
+    const int F = static_cast<int>(u >> 6);
+    const bool hiw = F < 4 * FM_HI;
+    const int wave = hiw ? F / FM_HI : 4 + (F - 4 * FM_HI) / FM_LO;
+    const int f = hiw ? F % FM_HI : (F - 4 * FM_HI) % FM_LO;
+    const int simd = wave & 3, NT = hiw ? HI_C : LO_C, F_DC3 = NT * KS_I;
+    const int cb = 32 * (simd * QC + (hiw ? 0 : HI_C));
+    const half_t* w;
+    int n0, ks, K;
+    if (f < F_DC3) {                                  // dc.3 [C][CI]
+        ks = f / NT; n0 = cb + 32 * (f % NT); w = w3; K = CI;
+    } else if (f < F_DC3 + F_FFN0) {                  // ffn.0 [4 CI][C]
+        const int g = f - F_DC3, pass = g / (TP * KS_C), r = g % (TP * KS_C);
+        ks = r / TP; n0 = wave * 32 * N0 + pass * 32 * TP + 32 * (r % TP); w = w0; K = C;
+    } else {                                          // ffn.2 [C][CI]
+        const int g = f - F_DC3 - F_FFN0;
+        ks = g / NT; n0 = cb + 32 * (g % NT); w = w2; K = CI;
+    }
+    out[u] = *reinterpret_cast<const half8*>(w + static_cast<size_t>(n0 + (lane & 31)) * K + 16 * ks + 8 * (lane >> 5));
+}
+
+__global__ void pack_dc08_kernel(const half_t* w1, int C, int CI, half8* out)       // dc.0 [CI][C]
+{
+    const int KS_C = C / 16, QI = CI / 128, HI_I = (QI + 1) / 2, LO_I = QI / 2, FD_HI = HI_I * KS_C, FD_LO = LO_I * KS_C;
+    const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (u >= 4LL * (FD_HI + FD_LO) * 64) return;
+    const int lane = static_cast<int>(u & 63);
+    const int F = static_cast<int>(u >> 6);
+    const bool hiw = F < 4 * FD_HI;
+    const int wave = hiw ? F / FD_HI : 4 + (F - 4 * FD_HI) / FD_LO;
+    const int f = hiw ? F % FD_HI : (F - 4 * FD_HI) % FD_LO;
+    const int simd = wave & 3, NT = hiw ? HI_I : LO_I;
+    const int ks = f / NT, n0 = 32 * (simd * QI + (hiw ? 0 : HI_I) + f % NT);
     out[u] = *reinterpret_cast<const half8*>(w1 + static_cast<size_t>(n0 + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5));
 }
 
 long long* g_ns_timeline = nullptr;
 
 }  // namespace
+
+int dcb_nsplit_waves();
 
 bool dcb_nsplit_shape(int c, int ci)
 {
@@ -67,8 +118,8 @@ void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, 
 {
     if (!dcb_nsplit_shape(c, ci)) throw std::invalid_argument("dcb_nsplit: unsupported block shape");
     const long long units = static_cast<long long>(dcb_nsplit_main_halves(c, ci) / 8);
-    hipLaunchKernelGGL(pack_main_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, stream, w3, w0, w2, c, ci,
-                       reinterpret_cast<half8*>(out));
+    hipLaunchKernelGGL(dcb_nsplit_waves() == 8 ? pack_main8_kernel : pack_main_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0,
+                       stream, w3, w0, w2, c, ci, reinterpret_cast<half8*>(out));
     hip_check(hipGetLastError(), "dcb_nsplit pack");
 }
 
@@ -76,9 +127,24 @@ void dcb_nsplit_pack_dc0(const half_t* w1, int c, int ci, half_t* out, hipStream
 {
     if (!dcb_nsplit_shape(c, ci)) throw std::invalid_argument("dcb_nsplit: unsupported block shape");
     const long long units = static_cast<long long>(dcb_nsplit_dc0_halves(c, ci) / 8);
-    hipLaunchKernelGGL(pack_dc0_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, stream, w1, c, ci,
-                       reinterpret_cast<half8*>(out));
+    hipLaunchKernelGGL(dcb_nsplit_waves() == 8 ? pack_dc08_kernel : pack_dc0_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0,
+                       stream, w1, c, ci, reinterpret_cast<half8*>(out));
     hip_check(hipGetLastError(), "dcb_nsplit pack");
+}
+
+#ifndef NS_WAVES_DEFAULT
+#define NS_WAVES_DEFAULT 8
+#endif
+int dcb_nsplit_waves()
+{
+    // waves per workgroup of the block kernel: 8 = dcb_nsplit8_kernel.h (round 4), 4 = dcb_nsplit_kernel.h (round 3; the A/B
+    // partner, DCVC_NSPLIT_WAVES=4). Read once: the packed weight streams of a process are laid out for one of the two.
+    static const int waves = [] {
+        const char* e = getenv("DCVC_NSPLIT_WAVES");
+        const int w = e != nullptr ? atoi(e) : NS_WAVES_DEFAULT;
+        return w == 4 ? 4 : 8;
+    }();
+    return waves;
 }
 
 int dcb_nsplit_mode()
@@ -119,6 +185,15 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     // (768-wide blocks - the hierarchical models' prior fusion at / 16 - have LDS for 32 pixels only)
     const bool wide = d.pixels >= 64 * 200 && d.c < 768;
     const bool next = d.wnext != nullptr;
+    if (dcb_nsplit_waves() == 8) {
+        if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
+        else if (d.c == 768) nsplit8::run_768_768(p, wide, next, stream);
+        else if (d.c == 512 && d.ci == 512) nsplit8::run_512_512(p, wide, next, stream);
+        else if (d.c == 512) nsplit8::run_512_256(p, wide, next, stream);
+        else if (d.ci == 256) nsplit8::run_256_256(p, wide, next, stream);
+        else nsplit8::run_256_128(p, wide, next, stream);
+        return;
+    }
     if (d.c == 384) run_384_384(p, wide, next, stream);
     else if (d.c == 768) run_768_768(p, wide, next, stream);
     else if (d.c == 512 && d.ci == 512) run_512_512(p, wide, next, stream);

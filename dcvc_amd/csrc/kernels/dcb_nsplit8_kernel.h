@@ -1,0 +1,560 @@
+// dcb_nsplit8_kernel.h - the N-split DepthConvBlock kernel (dcb_nsplit_kernel.h) with EIGHT waves per workgroup:
+// two per SIMD, 256 registers each, every wave owning an EIGHTH of a layer's output channels.
+//
+//     y1 = W3 * t2 + b3' + x                          dc.3 (+ folded depthwise bias) + block input
+//     t  = chunk_add(WSiLU(W0 * y1 + b0))             ffn.0   (4x expansion, never materialised)
+//     y  = (W2 * t + b2 + y1 [+ x]) [* q] -> fp16 [* q2]     ffn.2 (+ block shortcut, + quant scales)
+//     [t1' = WSiLU(W1' * y + b1')]                    dc.0 of the NEXT block of a chain (optional)
+//
+// Reference: DepthConvBlockProxy::forward, layers_proxy.cpp:71-101. Same contract, same arithmetic (contraction order,
+// bias-initialised accumulators, epilogue order, rounding points) as dcb_nsplit / conv_gemm: bit-identical
+// (tests/test_kernels_gpu.py) and equal to the oracle.
+//
+// Why (round 4, profiles/r04_phase_overlap.txt, tools/probes/phase_overlap.hip): a lone in-order wave per SIMD - round
+// 3's kernel - runs its MFMAs and its epilogue arithmetic one after the other: cutting an epilogue into pieces between
+// its own MFMAs hid 13 - 40 % of it, and a third of the tile was epilogue time with the matrix core idle. TWO waves on
+// a SIMD that each alternate [contraction] [own epilogue] fall out of step by themselves (they compete for the one
+// matrix pipe) and then overlap: the probe's 96 MFMAs + 600 VALU per SIMD take 5 914 cycles on one wave and 3 793 on
+// two; with LDS gathers in the epilogue 23.0 k against 11.9 k. So here:
+//   * 8 waves; waves w and w + 4 share a SIMD (a workgroup's waves are dealt out cyclically over the four SIMDs) and
+//     between them own a QUARTER of a layer's 32-channel tiles - split evenly where the quarter is even, 2 + 1 for the
+//     384-wide layers (wave w the larger share), 1 + 0 for dc.0 of the (256, 128) blocks; ffn.0's 4 CI channels split
+//     evenly over all eight waves, in passes of 2 tiles;
+//   * every wave streams ITS weight fragments (packed per wave, dcb_nsplit.hip) into an 8-fragment register ring by
+//     buffer_load; the workgroup as a whole still reads each weight byte once per 64 pixels;
+//   * no software pipelining inside a wave: a pass is [MFMAs] [its WSiLU + chunk-add epilogue], the partner wave fills
+//     the matrix pipe meanwhile. One accumulator set: 256 registers suffice.
+// Everything else as dcb_nsplit: activations in LDS (A = [PX][CI], B = [PX][C], XOR-swizzled), persistent workgroups,
+// the next tile's t2 by LDS-DMA behind ffn.2's MFMAs, outputs stored straight from the epilogues' registers.
+#pragma once
+#include "dcb_nsplit_kernel.h"
+
+namespace dcvc {
+namespace nsplit8 {
+
+using nsplit::align16k;
+using nsplit::lds_dma16;
+using nsplit::NsParams;
+using nsplit::R;
+using nsplit::static_for;
+using nsplit::TABLE_BYTES;
+using nsplit::uint4v;
+
+constexpr int NTHREADS = 512;
+#ifndef NS8_RING
+#define NS8_RING 8
+#endif
+constexpr int RING = NS8_RING;           // weight fragments in flight per wave (4 registers each)
+#ifndef NS8_GATHERS
+#define NS8_GATHERS 8
+#endif
+constexpr int GB = NS8_GATHERS;          // table gathers in flight in the WSiLU epilogues (4 registers each)
+
+// Per-wave tile / fragment counts. A "tile" = 32 output channels; a fragment = one MFMA "A" operand (32 channels x 16 k).
+template <int C, int CI>
+struct Geo {
+    static constexpr int KS_C = C / 16, KS_I = CI / 16;
+    static constexpr int QC = C / 128, QI = CI / 128;                  // tiles per SIMD pair of a C- / CI-wide layer
+    static constexpr int HI_C = (QC + 1) / 2, LO_C = QC / 2;           // ... of which wave w < 4 / wave w + 4
+    static constexpr int HI_I = (QI + 1) / 2, LO_I = QI / 2;
+    static constexpr int N0 = CI / 64;                                  // ffn.0 tiles per wave (4 CI / 32 / 8)
+    static constexpr int TP = 2, NP = N0 / TP;                          // passes of 2 tiles
+    static constexpr bool EVEN = HI_C == LO_C && HI_I == LO_I;
+    static constexpr int nt_c(bool hiw) { return hiw ? HI_C : LO_C; }
+    static constexpr int nt_i(bool hiw) { return hiw ? HI_I : LO_I; }
+    static constexpr int f_dc3(bool hiw) { return nt_c(hiw) * KS_I; }
+    static constexpr int F_FFN0 = N0 * KS_C;
+    static constexpr int f_main(bool hiw) { return 2 * f_dc3(hiw) + F_FFN0; }
+    static constexpr int f_dc0(bool hiw) { return nt_i(hiw) * KS_C; }
+    static_assert(C % 128 == 0 && CI % 128 == 0 && N0 % TP == 0, "channel counts in units of 4 SIMDs x 32");
+};
+
+template <int C, int CI, int PXT, bool NEXT, bool HIW>
+__device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
+{
+    using G = Geo<C, CI>;
+    constexpr int PX = 32 * PXT;
+    constexpr int KS_C = G::KS_C, KS_I = G::KS_I;
+    constexpr int NT_C = G::nt_c(HIW), NT_I = G::nt_i(HIW), NP = G::NP, TP = G::TP;
+    constexpr int F_DC3 = G::f_dc3(HIW), F_FFN0 = G::F_FFN0, F_MAIN = G::f_main(HIW), F_DC0 = G::f_dc0(HIW);
+    constexpr int CH_C = C / 8, CH_I = CI / 8;                  // 16-byte chunks per row
+    constexpr int PITCH_C = C * 2, PITCH_I = CI * 2;
+    constexpr int BUF_A = PX * PITCH_I, BUF_B = PX * PITCH_C;
+    constexpr int OFF_B = BUF_A;
+    constexpr int OFF_TABLE = align16k(BUF_A + BUF_B);
+    constexpr int OFF_BIAS = OFF_TABLE + R * TABLE_BYTES;           // fp32: b3 (C) | b0 (4 CI) | b2 (C) | b1n (CI)
+    constexpr int BIAS_FLOATS = 2 * C + 5 * CI;
+    constexpr int OFF_Q = OFF_BIAS + BIAS_FLOATS * 4;               // fp16: q | q2
+    constexpr int TOTAL = F_MAIN + (NEXT ? F_DC0 : 0);
+    static_assert((PX * CH_C) % NTHREADS == 0 && (PX * CH_I) % NTHREADS == 0, "tile rows must split evenly over the threads");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int simd = wave & 3;                            // the SIMD pair (waves simd, simd + 4)
+    const int px = lane & 31;
+    const int hi = lane >> 5;
+    const int ntiles = (p.M + PX - 1) / PX;
+    int tile = blockIdx.x;                               // persistent: tiles blockIdx.x, + gridDim.x, ...
+    int m0 = tile * PX;
+    const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)smem));
+    if ((lds_base & 16383u) != 0) __builtin_trap();      // dynamic LDS starts at 0 (no static LDS in this kernel)
+    // first channel of this wave's share of a C-wide / CI-wide layer, of ffn.0's 4 CI channels, of t
+    // (HIW = the body of the waves with the larger share; where the shares are equal every wave runs it)
+    const bool upper = wave >= 4;
+    const int cb_c = 32 * (simd * G::QC + (upper ? G::HI_C : 0));
+    const int cb_i = 32 * (simd * G::QI + (upper ? G::HI_I : 0));
+    const int cb_0 = wave * (32 * G::N0);
+    // stamps (wave 0, first tile): 0 entry | 1 constants + first t2 in LDS | 2 dc.3 done (barrier) | one per ffn.0 pass |
+    // ffn.0 done (barrier) | ffn.2 MFMAs | ffn.2 done | dc.0 MFMAs | dc.0 done
+    int stamp_no = 0;
+    auto stamp = [&]() {
+        if (p.timeline != nullptr && tid == 0 && stamp_no < 32 && tile == static_cast<int>(blockIdx.x)) {
+            p.timeline[static_cast<size_t>(blockIdx.x) * 32 + stamp_no] = static_cast<long long>(__builtin_readcyclecounter());
+        }
+        ++stamp_no;
+    };
+    stamp();
+
+    // ---- constants into registers first (all loads independent), written to LDS behind the first tile's transfers
+    constexpr int TAB_PER_THREAD = R * WSILU_SEGMENTS / NTHREADS;
+    static_assert(TAB_PER_THREAD == 2, "two table rows per thread, spelled out");
+    const float4 tab0 = p.wsilu[tid / R], tab1 = p.wsilu[(tid + NTHREADS) / R];
+    constexpr int CONST_UNITS = (BIAS_FLOATS + 2 * C) / 8;      // b3 | b0 | b2 | b1n | q | q2 in 8-channel units
+    constexpr int CONST_PER_THREAD = (CONST_UNITS + NTHREADS - 1) / NTHREADS;
+    static_assert(CONST_PER_THREAD <= 2, "two named registers below");
+    auto const_unit = [&](int k) {
+        const int ch = min(tid + k * NTHREADS, CONST_UNITS - 1) * 8;
+        const half_t* src = ch < C ? p.b3 + ch
+                          : ch < C + 4 * CI ? p.b0 + (ch - C)
+                          : ch < 2 * C + 4 * CI ? p.b2 + (ch - C - 4 * CI)
+                          : ch < BIAS_FLOATS ? (p.b1n != nullptr ? p.b1n + (ch - 2 * C - 4 * CI) : p.b2)
+                          : ch < BIAS_FLOATS + C ? (p.q != nullptr ? p.q + (ch - BIAS_FLOATS) : p.b2)
+                          : (p.q2 != nullptr ? p.q2 + (ch - BIAS_FLOATS - C) : p.b2);
+        return *reinterpret_cast<const half8*>(src);
+    };
+    const half8 cv0 = const_unit(0), cv1 = const_unit(CONST_PER_THREAD > 1 ? 1 : 0);
+    const float* const lb3 = reinterpret_cast<const float*>(smem + OFF_BIAS);
+    const float* const lb0 = lb3 + C;
+    const float* const lb2 = lb3 + C + 4 * CI;
+    const float* const lb1n = lb3 + 2 * C + 4 * CI;
+    const half_t* const lq = reinterpret_cast<const half_t*>(smem + OFF_Q);
+    const half_t* const lq2 = lq + C;
+    unsigned tab = lds_base + OFF_TABLE + (lane & (R - 1)) * 16;
+
+    // ---- the wave's weight streams (dcb_nsplit.hip pack_*8): waves 0 .. 3 first (their share may be the larger one),
+    // then 4 .. 7; fragment f of a wave at 1 KB f from the wave's base, lane-linear. Buffer loads: lane offset + 12-bit
+    // immediate + one scalar offset per 4 KB, no VALU per fragment.
+    constexpr int FM_HI = G::f_main(true), FM_LO = G::f_main(false), FD_HI = G::f_dc0(true), FD_LO = G::f_dc0(false);
+    unsigned wsm = static_cast<unsigned>((HIW ? wave * FM_HI : 4 * FM_HI + (wave - 4) * FM_LO) * 64 + lane) * 16u;
+    unsigned wsn = static_cast<unsigned>((HIW ? wave * FD_HI : 4 * FD_HI + (wave - 4) * FD_LO) * 64 + lane) * 16u;
+    const __amdgpu_buffer_rsrc_t rs_main = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8*>(p.wmain), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8*>(NEXT ? p.wnext : p.wmain), 0, 0x7fffffff, 0x00020000);
+    half8 ring[RING];
+    auto issue = [&](auto f_tag) {
+        constexpr int f = decltype(f_tag)::value;
+        if constexpr (f < F_MAIN) {
+            ring[f % RING] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_main, wsm + static_cast<unsigned>(f & 3) * 1024u, (f >> 2) * 4096, 0));
+        } else if constexpr (f < TOTAL) {
+            constexpr int g = f - F_MAIN;
+            ring[f % RING] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_next, wsn + static_cast<unsigned>(g & 3) * 1024u, (g >> 2) * 4096, 0));
+        }
+    };
+    // ---- a [PX][W] tile of whole rows, memory -> LDS by LDS-DMA; LDS image lane-linear, the bank swizzle (16-byte
+    // chunk c of row r lives at chunk c ^ (r & 15)) sits on the SOURCE side. Rows behind the picture read its last row.
+    int tidv = tid;
+    auto dma_tile = [&](auto chunks_tag, const half_t* base, int ld, unsigned lds_off, int first_row) {
+        constexpr int CHN = decltype(chunks_tag)::value;
+        const int f = min(first_row, p.M - 1);
+        const int last = p.M - 1 - f;
+        const half_t* const w = base + static_cast<size_t>(f) * ld;
+#pragma unroll
+        for (int i = 0; i < PX * CHN / NTHREADS; ++i) {
+            const int pos = i * NTHREADS + tidv;
+            const int r = pos / CHN, pc = pos % CHN;
+            const int lc = pc ^ (r & 15);
+            const int rr = min(r, last);
+            lds_dma16(w, static_cast<unsigned>(rr * ld + lc * 8) * 2u, lds_base + lds_off + (i * NTHREADS + wave * 64) * 16);
+        }
+    };
+    using ChI = std::integral_constant<int, CH_I>;
+    // ---- the block input x of a tile (dc.3's residual) waits in registers, in the layout of dc.3's epilogue
+    half8 xr[NT_C > 0 ? NT_C : 1][PXT][2];
+    int pxv = px, hiv = hi;
+    auto load_x = [&](int first_row) {
+#pragma unroll
+        for (int t = 0; t < PXT; ++t) {
+            const half_t* const row = p.x + static_cast<size_t>(min(first_row + 32 * t + pxv, p.M - 1)) * p.ldx + (cb_c + 8 * hiv);
+#pragma unroll
+            for (int j = 0; j < NT_C; ++j)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) xr[j][t][pr] = *reinterpret_cast<const half8*>(row + 32 * j + 16 * pr);
+        }
+    };
+    // first tile: t2 -> A, the first weight fragments, x; then the constants go to LDS
+    dma_tile(ChI{}, p.t2, p.ldt, 0, m0);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, RING>([&](auto i) { issue(i); });
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(m0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX * CH_I / NTHREADS + RING + NT_C * PXT * 2) : "memory");     // the constants have arrived
+    {
+        float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
+        t[tid] = tab0; t[tid + NTHREADS] = tab1;
+        float* lb = reinterpret_cast<float*>(smem + OFF_BIAS);
+        half_t* lqw = reinterpret_cast<half_t*>(smem + OFF_Q);
+        auto put = [&](int k, const half8 v) {
+            const int u = tid + k * NTHREADS;
+            if (u < BIAS_FLOATS / 8) {
+                float4v lo4, hi4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo4[e] = static_cast<float>(v[e]);
+                    hi4[e] = static_cast<float>(v[4 + e]);
+                }
+                *reinterpret_cast<float4v*>(lb + u * 8) = lo4;
+                *reinterpret_cast<float4v*>(lb + u * 8 + 4) = hi4;
+            } else if (u < CONST_UNITS) {
+                *reinterpret_cast<half8*>(lqw + (u - BIAS_FLOATS / 8) * 8) = v;
+            }
+        };
+        put(0, cv0);
+        if (CONST_PER_THREAD > 1) put(1, cv1);
+    }
+    // this wave's pieces of t2 have landed (x, requested last, may still be on its way: dc.3's epilogue is its first use)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT_C * PXT * 2) : "memory");
+    __syncthreads();
+    stamp();
+
+    // ---- fragment addressing. Row of pixel tile t: (32 t + px) * pitch; chunk c of a row sits at c ^ (px & 15).
+    // B fragment of k-slice ks: chunk 2 ks + hi = (2 ks) ^ hi: (32 ks) ^ s0 = ((32 (ks & 7)) ^ s0) + 256 (ks >> 3).
+    int s0 = (hi ^ (px & 15)) << 4;
+    int rowA = px * PITCH_I, rowB = px * PITCH_C + OFF_B;     // byte offsets from smem
+    int hi4 = 4 * hi;
+    int fa8[8], fb8[8];
+    auto frag_a = [&](int t, int ks) { return *reinterpret_cast<const half8*>(smem + fa8[ks & 7] + (t * (32 * PITCH_I) + (ks >> 3) * 256)); };
+    auto frag_b = [&](int t, int ks) { return *reinterpret_cast<const half8*>(smem + fb8[ks & 7] + (t * (32 * PITCH_C) + (ks >> 3) * 256)); };
+    // the 16-byte run of channels ch0 + 8 hi .. + 7 (ch0 a multiple of 16) of this lane's pixel in tile t
+    auto run_a = [&](int t, int ch0) { return reinterpret_cast<half8*>(smem + rowA + t * (32 * PITCH_I) + ((ch0 * 2) ^ s0)); };
+    auto run_b = [&](int t, int ch0) { return reinterpret_cast<half8*>(smem + rowB + t * (32 * PITCH_C) + ((ch0 * 2) ^ s0)); };
+    // accumulator tile (32 channels from `first`) initialised with the bias: acc[r] = channel first + 8 (r>>2) + 4 hi + (r&3)
+    auto bias_tile = [&](float16v& acc, const float* bias, int first) {
+        const float* bp = bias + first + hi4;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4v b4 = *reinterpret_cast<const float4v*>(bp + 8 * g4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g4 + e] = b4[e];
+        }
+    };
+    // accumulator tile -> run pr: channels 16 pr + 8 hi .. + 7 of the tile, this lane's pixel (half-waves paired up)
+    auto runs_of = [&](const float16v& a, int pr, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * pr + e]), __float_as_uint(a[8 * pr + 4 + e]), false, false);
+            v[e] = __uint_as_float(sw[0]);
+            v[4 + e] = __uint_as_float(sw[1]);
+        }
+    };
+    // NT tiles x PXT pixel tiles over KSN k-slices (fragment F0 + ks NT + j), activations through `frag` (A or B)
+    auto contract = [&](auto nt_tag, auto ks_tag, auto f0_tag, auto&& frag, auto& acc) {
+        constexpr int NT = decltype(nt_tag)::value;
+        constexpr int KSN = decltype(ks_tag)::value;
+        constexpr int F0 = decltype(f0_tag)::value;
+        half8 b[2][PXT];              // activation fragments, read one k-slice ahead of their MFMAs
+#pragma unroll
+        for (int t = 0; t < PXT; ++t) b[0][t] = frag(t, 0);
+        static_for<0, KSN>([&](auto kt) {
+            constexpr int ks = decltype(kt)::value;
+            if constexpr (ks + 1 < KSN) {
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) b[(ks + 1) & 1][t] = frag(t, ks + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NT>([&](auto j_tag) {
+                constexpr int j = NT - 1 - decltype(j_tag)::value;       // the slice's LAST fragment first: one counted wait per slice
+                const half8 a = ring[(F0 + ks * NT + j) % RING];
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks & 1][t], acc[j][t], 0, 0, 0);
+            });
+            static_for<0, NT>([&](auto j_tag) { issue(std::integral_constant<int, F0 + ks * NT + decltype(j_tag)::value + RING>{}); });
+            // nothing crosses a k-slice (left alone, hipcc sinks every prefetch load down to the MFMA that consumes it)
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using KsC = std::integral_constant<int, KS_C>;
+    using KsI = std::integral_constant<int, KS_I>;
+
+    // ================================================================ persistent loop over this workgroup's tiles
+    for (;;) {
+    // (made opaque once per tile: as loop invariants every derived address would be hoisted out of the loop and spilled)
+    asm volatile("" : "+v"(wsm), "+v"(wsn), "+v"(tab), "+v"(s0), "+v"(rowA), "+v"(rowB), "+v"(hi4), "+v"(tidv), "+v"(pxv), "+v"(hiv));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        fa8[i] = rowA + ((32 * i) ^ s0);
+        fb8[i] = rowB + ((32 * i) ^ s0);
+    }
+    const int next_tile = tile + static_cast<int>(gridDim.x);
+    const bool has_next = next_tile < ntiles;
+    // ================================================================ dc.3: y1 = W3 t2 + b3' + x   (A -> B)
+    if constexpr (NT_C > 0) {
+        float16v acc[NT_C][PXT];
+#pragma unroll
+        for (int j = 0; j < NT_C; ++j)
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, cb_c + 32 * j);
+        contract(std::integral_constant<int, NT_C>{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc);
+#pragma unroll
+        for (int j = 0; j < NT_C; ++j)
+#pragma unroll
+            for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float v[8];
+                    runs_of(acc[j][t], pr, v);
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[j][t][pr][e]));
+                    *run_b(t, cb_c + 32 * j + 16 * pr) = o;
+                }
+    }
+    __syncthreads();            // y1 complete in B; every wave is done with t2 in A
+    stamp();
+
+    // ================================================================ ffn.0: t = chunk_add(WSiLU(W0 y1 + b0))   (B -> A)
+    // The wave's 32 N0 ffn.0 channels in NP passes of TP = 2 tiles: a pass = 64 ffn.0 channels = 16 channels of t
+    // (the lower half-wave collects the 8 of the pass's first tile, the upper half-wave those of the second).
+    {
+        float16v acc[TP][PXT];
+        static_for<0, NP>([&](auto pass_tag) {
+            constexpr int pass = decltype(pass_tag)::value;
+            const int f0 = cb_0 + pass * (32 * TP);        // first ffn.0 channel of the pass
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb0, f0 + 32 * j);
+            contract(std::integral_constant<int, TP>{}, KsC{}, std::integral_constant<int, F_DC3 + pass * TP * KS_C>{}, frag_b, acc);
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) {
+                float sums[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int g0 = 0; g0 < 16; g0 += GB) {
+                        float4v c[GB];
+#pragma unroll
+                        for (int e = 0; e < GB; ++e) {
+                            const float4 r = wsilu_row_lds<R, true>(acc[h][t][g0 + e], tab);
+                            c[e] = float4v{r.x, r.y, r.z, r.w};
+                        }
+#pragma unroll
+                        for (int g = 0; g < GB / 4; ++g) {
+                            auto row = [&](int e) { const float4v r = c[4 * g + e]; return make_float4(r[0], r[1], r[2], r[3]); };
+                            const int v0 = g0 + 4 * g;
+                            float s = acc[h][t][v0] * wsilu_poly(acc[h][t][v0], row(0));
+#pragma unroll
+                            for (int e = 1; e < 4; ++e) s = fmaf(acc[h][t][v0 + e], wsilu_poly(acc[h][t][v0 + e], row(e)), s);
+                            sums[h][g0 / 4 + g] = s;
+                        }
+                    }
+                }
+                half8 o;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sums[0][g]), __float_as_uint(sums[1][g]), false, false);
+                    o[2 * g] = to_half(__uint_as_float(sw[0]));
+                    o[2 * g + 1] = to_half(__uint_as_float(sw[1]));
+                }
+                *run_a(t, f0 / 4) = o;                 // t channels f0 / 4 + 8 hi .. + 7
+            }
+            stamp();
+        });
+    }
+    __syncthreads();            // t complete in A; every wave is done with y1 as an operand
+    stamp();
+
+    // ================================================================ ffn.2: y = (W2 t + b2 + y1 [+ x]) [* q] -> fp16 [* q2]   (A -> B in place of y1)
+    {
+        float16v acc[NT_C > 0 ? NT_C : 1][PXT];
+        if constexpr (NT_C > 0) {
+#pragma unroll
+            for (int j = 0; j < NT_C; ++j)
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, cb_c + 32 * j);
+            contract(std::integral_constant<int, NT_C>{}, KsI{}, std::integral_constant<int, F_DC3 + F_FFN0>{}, frag_a, acc);
+        }
+        stamp();
+        // the next tile's transfers: t is dead once every wave is behind its last ffn.2 MFMA. They go out in front of
+        // the epilogue, which needs no weights (a transfer from memory in front of a contraction holds up every weight
+        // fragment requested behind it: loads return in order)
+        __syncthreads();
+        if (has_next) dma_tile(ChI{}, p.t2, p.ldt, 0, next_tile * PX);
+        if constexpr (NT_C > 0) load_x(next_tile * PX);        // (unconditional - rows are clamped to the picture)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT_C; ++j)
+#pragma unroll
+            for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int ch = cb_c + 32 * j + 16 * pr;          // + 8 hi
+                    float v[8];
+                    runs_of(acc[j][t], pr, v);
+                    half8* const slot = run_b(t, ch);
+                    const half8 y1 = *slot;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(y1[e]);
+                    if (p.shortcut) {
+                        const int m = min(m0 + 32 * t + px, p.M - 1);
+                        const half8 r8 = *reinterpret_cast<const half8*>(p.x + static_cast<size_t>(m) * p.ldx + ch + 8 * hi);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
+                    }
+                    if (p.q != nullptr) {
+                        const half8 q8 = *reinterpret_cast<const half8*>(lq + ch + 8 * hi);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                    if (p.q2 != nullptr) {
+                        const half8 q8 = *reinterpret_cast<const half8*>(lq2 + ch + 8 * hi);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
+                    }
+                    if constexpr (NEXT) *slot = o;          // dc.0's operand
+                    const int m = m0 + 32 * t + pxv;
+                    if (m < p.M) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
+                }
+    }
+    if constexpr (NEXT) __syncthreads();            // y complete in B
+    stamp();
+
+    // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')   (B -> memory)
+    if constexpr (NEXT && NT_I > 0) {
+        float16v acc[NT_I][PXT];
+#pragma unroll
+        for (int j = 0; j < NT_I; ++j)
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, cb_i + 32 * j);
+        contract(std::integral_constant<int, NT_I>{}, KsC{}, std::integral_constant<int, F_MAIN>{}, frag_b, acc);
+        // the ring is empty: the first fragments of the next tile go out now and arrive under the epilogue below
+        if (has_next) {
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, RING>([&](auto i) { issue(i); });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp();
+#pragma unroll
+        for (int j = 0; j < NT_I; ++j)
+#pragma unroll
+            for (int t = 0; t < PXT; ++t)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float v[8];
+                    runs_of(acc[j][t], pr, v);
+                    float4v c[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float4 r = wsilu_row_lds<R, true>(v[e], tab);
+                        c[e] = float4v{r.x, r.y, r.z, r.w};
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], make_float4(c[e][0], c[e][1], c[e][2], c[e][3])));
+                    const int m = m0 + 32 * t + pxv;
+                    if (m < p.M) store_line(p.t1n + static_cast<size_t>(m) * p.ldt1 + cb_i + 32 * j + 16 * pr + 8 * hiv, o);
+                }
+    } else {
+        if (has_next) {
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, RING>([&](auto i) { issue(i); });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp();
+    }
+    stamp();
+    if (!has_next) break;
+    // the next tile's t2 has landed (every wave waits for its own pieces, the barrier covers the others'); every wave is
+    // done with y in B: B is free for the next tile's y1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tile = next_tile;
+    m0 = tile * PX;
+    }       // tiles
+    // stamp 31: the workgroup's last instruction (all tiles): cycles of the whole launch per workgroup -> effective clock
+    if (p.timeline != nullptr && tid == 0) p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 31] = static_cast<long long>(__builtin_readcyclecounter());
+}
+
+template <int C, int CI, int PXT, bool NEXT>
+__global__ void __launch_bounds__(NTHREADS, 2)
+dcb_nsplit8_kernel(const NsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem8[];
+    if constexpr (Geo<C, CI>::EVEN) {
+        block_body<C, CI, PXT, NEXT, true>(p, smem8);
+    } else {
+        // the waves of a SIMD pair own different numbers of tiles: two bodies, one barrier sequence
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) block_body<C, CI, PXT, NEXT, true>(p, smem8);
+        else block_body<C, CI, PXT, NEXT, false>(p, smem8);
+    }
+}
+
+template <int C, int CI, int PXT, bool NEXT>
+void launch8(const NsParams& p, hipStream_t stream)
+{
+    auto kern = dcb_nsplit8_kernel<C, CI, PXT, NEXT>;
+    constexpr int smem = nsplit::smem_bytes<C, CI, PXT>();
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    constexpr int MAX_DEVICES = 64;
+    static std::once_flag once[MAX_DEVICES];
+    static int cu_count[MAX_DEVICES];
+    int dev = 0;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    if (dev < 0 || dev >= MAX_DEVICES) throw std::runtime_error("dcb_nsplit8: device id out of range");
+    std::call_once(once[dev], [&] {
+        hipDeviceProp_t prop;
+        hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+            throw std::runtime_error(std::string("dcb_nsplit8 needs gfx950 (160 KB LDS, permlane32_swap); device is ") + prop.gcnArchName);
+        }
+        hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
+                  "hipFuncSetAttribute(dcb_nsplit8)");
+        int n = 0;
+        hip_check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
+        cu_count[dev] = n > 0 ? n : 256;
+    });
+    const int cus = cu_count[dev];
+    const int tiles = (p.M + 32 * PXT - 1) / (32 * PXT);
+    const int grid = tiles < cus ? tiles : cus;
+    hipEvent_t ev0, ev1;
+    const int kflop = (NEXT ? 7 : 6) * CI;
+    if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x40000000, 0.f}, &ev0, &ev1)) {
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, ev0, ev1, 0, p);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, p);
+    }
+    hip_check(hipGetLastError(), "dcb_nsplit8 launch");
+}
+
+template <int C, int CI>
+void run_shape8(const NsParams& p, bool wide, bool next, hipStream_t stream)
+{
+    if constexpr (C < 768) {
+        if (wide) { if (next) launch8<C, CI, 2, true>(p, stream); else launch8<C, CI, 2, false>(p, stream); return; }
+    }
+    if (next) launch8<C, CI, 1, true>(p, stream); else launch8<C, CI, 1, false>(p, stream);
+}
+
+// dcb_nsplit8_<shape>.hip
+void run_256_128(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_256_256(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_384_384(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_512_256(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_512_512(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_768_768(const NsParams& p, bool wide, bool next, hipStream_t stream);
+
+}  // namespace nsplit8
+}  // namespace dcvc

@@ -61,6 +61,38 @@ constexpr int NTHREADS = 256;
 #define NS_RING 16
 #endif
 constexpr int RING_DEFAULT = NS_RING;    // weight fragments in flight per wave (4 registers each)
+// Round-4 switches (each bit-identical; defaults = what measured best, profiles/r04_core_bench_*.txt):
+//   NS_CHMAJOR  dc.3 / ffn.2 / dc.0 walk the wave's channel tiles ONE AFTER THE OTHER (each over all k-slices) instead of
+//               all tiles per k-slice: the epilogue of tile j - cut into 2 PXT runs - issues beside the MFMAs of tile
+//               j + 1, so only the LAST tile's epilogue (a third of it) is exposed, and the output stores spread over the
+//               phase instead of leaving in one burst. Changes the order of the packed weight stream (dcb_nsplit.hip).
+//   NS_XEARLY   where the next tile's x is requested: 0 = in front of dc.0's epilogue (round 3), 1 = in front of the last
+//               ffn.0 pass's (exposed) epilogue - one transfer burst per exposed epilogue: x | t2 + y | t1' -, 2 = with t2
+//               behind ffn.2's MFMAs (x + t2 + y | t1')
+//   NS_WAITLAST within a k-slice the LAST fragment of the slice feeds the first MFMAs: one counted wait per slice
+#ifndef NS_CHMAJOR
+#define NS_CHMAJOR 0
+#endif
+#ifndef NS_XEARLY
+#define NS_XEARLY 2
+#endif
+#ifndef NS_WAITLAST
+#define NS_WAITLAST 1
+#endif
+//   NS_BUFLOAD  weight fragments by buffer_load (resource = the packed stream, lane offset + 12-bit immediate + a scalar
+//               offset per 4 KB) instead of global_load with a VALU addition per fragment beyond the immediate's reach
+//   NS_ADDR8    the 8 distinct swizzled LDS row addresses of the activation fragments (k-slice mod 8) live in registers,
+//               everything else of a fragment's address is the instruction's immediate: no VALU per fragment read
+#ifndef NS_BUFLOAD
+#define NS_BUFLOAD 1
+#endif
+#ifndef NS_ADDR8
+#define NS_ADDR8 1
+#endif
+constexpr bool CHMAJOR = NS_CHMAJOR != 0, WAITLAST = NS_WAITLAST != 0;
+constexpr int XEARLY = NS_XEARLY;
+constexpr bool BUFLOAD = NS_BUFLOAD != 0, ADDR8 = NS_ADDR8 != 0;
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 constexpr int R = 4;                     // interleaved copies of the WSiLU table
 constexpr int TABLE_BYTES = WSILU_SEGMENTS * 16;
 constexpr int align16k(int bytes) { return (bytes + 16383) & ~16383; }
@@ -138,7 +170,7 @@ dcb_nsplit_kernel(const NsParams p)
 #endif
     // Output rows (bit 0: t1', bit 1: y) are stored straight from the epilogues' registers - 16 bytes per lane, half-waves
     // pairing up to 32-byte pieces of a row, L2 merges the pieces of a line - instead of staged in LDS, synchronised and
-    // copied out as whole rows: a barrier and a 2 k-cycle copy less per output (A/B on one box, tools/r3_session17.sh:
+    // copied out as whole rows: a barrier and a 2 k-cycle copy less per output (A/B on one box, round 3:
     // intra 80.8 -> 83.8, HT-S 430 -> 443 pictures/s on a throttled box; every shape of the block bench equal or faster).
     // NS_DIRECT=0 builds the staged form.
     constexpr bool DIRECT_T1 = (NS_DIRECT & 1) != 0, DIRECT_Y = (NS_DIRECT & 2) != 0;
@@ -220,6 +252,9 @@ dcb_nsplit_kernel(const NsParams p)
     // counts on lgkmcnt as well and turns every counted wait into vmcnt(0) - measured: the walk 50 % slower.)
     unsigned wsm = static_cast<unsigned>(wave * G::F_MAIN * 64 + lane) * 16u;
     unsigned wsn = static_cast<unsigned>(wave * G::F_DC0 * 64 + lane) * 16u;
+    // (NS_BUFLOAD: the streams as buffer resources - base, no stride, no bounds in the way, raw dword format)
+    const __amdgpu_buffer_rsrc_t rs_main = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8*>(p.wmain), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8*>(NEXT ? p.wnext : p.wmain), 0, 0x7fffffff, 0x00020000);
     // Fragment f of the stream lives in ring[f % RING] from its load (issued RING fragments ahead) to its MFMAs
     half8 ring[RING];
     // Ablation switches (tools/build_variant.sh; RESULTS ARE WRONG with any of them): NS_EXP_NOLOAD = no weight loads
@@ -230,9 +265,18 @@ dcb_nsplit_kernel(const NsParams p)
         if constexpr (f >= RING) return;
 #endif
         if constexpr (f < G::F_MAIN) {
-            ring[f % RING] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.wmain) + (wsm + static_cast<unsigned>(f) * 1024u));
+            if constexpr (BUFLOAD) {
+                ring[f % RING] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_main, wsm + static_cast<unsigned>(f & 3) * 1024u, (f >> 2) * 4096, 0));
+            } else {
+                ring[f % RING] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.wmain) + (wsm + static_cast<unsigned>(f) * 1024u));
+            }
         } else if constexpr (f < TOTAL) {
-            ring[f % RING] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.wnext) + (wsn + static_cast<unsigned>(f - G::F_MAIN) * 1024u));
+            constexpr int g = f - G::F_MAIN;
+            if constexpr (BUFLOAD) {
+                ring[f % RING] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_next, wsn + static_cast<unsigned>(g & 3) * 1024u, (g >> 2) * 4096, 0));
+            } else {
+                ring[f % RING] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.wnext) + (wsn + static_cast<unsigned>(g) * 1024u));
+            }
         }
     };
     // ---- a [PX][W] tile of whole rows, memory -> LDS by LDS-DMA; LDS image lane-linear, the bank swizzle (16-byte
@@ -311,8 +355,16 @@ dcb_nsplit_kernel(const NsParams p)
     int s0 = (hi ^ (px & 15)) << 4;
     int rowA = px * PITCH_I, rowB = px * PITCH_C + OFF_B;     // byte offsets from smem
     int hi4 = 4 * hi;                 // (bias_tile)
-    auto frag_a = [&](int t, int ks) { return *reinterpret_cast<const half8*>(smem + rowA + t * (32 * PITCH_I) + ((ks * 32) ^ s0)); };
-    auto frag_b = [&](int t, int ks) { return *reinterpret_cast<const half8*>(smem + rowB + t * (32 * PITCH_C) + ((ks * 32) ^ s0)); };
+    // (NS_ADDR8: (32 ks) ^ s0 = ((32 (ks & 7)) ^ s0) + 256 (ks >> 3): s0 has bits 4 .. 7 only)
+    int fa8[8], fb8[8];
+    auto frag_a = [&](int t, int ks) {
+        if constexpr (ADDR8) return *reinterpret_cast<const half8*>(smem + fa8[ks & 7] + (t * (32 * PITCH_I) + (ks >> 3) * 256));
+        else return *reinterpret_cast<const half8*>(smem + rowA + t * (32 * PITCH_I) + ((ks * 32) ^ s0));
+    };
+    auto frag_b = [&](int t, int ks) {
+        if constexpr (ADDR8) return *reinterpret_cast<const half8*>(smem + fb8[ks & 7] + (t * (32 * PITCH_C) + (ks >> 3) * 256));
+        else return *reinterpret_cast<const half8*>(smem + rowB + t * (32 * PITCH_C) + ((ks * 32) ^ s0));
+    };
     // the 16-byte run of channels ch0 + 8 hi .. + 7 (ch0 a multiple of 16) of this lane's pixel in tile t
     auto run_a = [&](int t, int ch0) { return reinterpret_cast<half8*>(smem + rowA + t * (32 * PITCH_I) + ((ch0 * 2) ^ s0)); };
     auto run_b = [&](int t, int ch0) { return reinterpret_cast<half8*>(smem + rowB + t * (32 * PITCH_C) + ((ch0 * 2) ^ s0)); };
@@ -353,7 +405,7 @@ dcb_nsplit_kernel(const NsParams p)
             }
             __builtin_amdgcn_sched_barrier(0);       // ... and stay in front of this slice's MFMAs
             static_for<0, NT>([&](auto j_tag) {
-                constexpr int j = decltype(j_tag)::value;
+                constexpr int j = WAITLAST ? NT - 1 - decltype(j_tag)::value : decltype(j_tag)::value;
                 const half8 a = ring[(F0 + ks * NT + j) % RING];
 #pragma unroll
                 for (int t = 0; t < PXT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks & 1][t], acc[j][t], 0, 0, 0);
@@ -371,6 +423,53 @@ dcb_nsplit_kernel(const NsParams p)
     using KsC = std::integral_constant<int, KS_C>;
     using KsI = std::integral_constant<int, KS_I>;
     auto no_piece = [](int) {};
+    // NS_CHMAJOR: MT channel tiles one after the other (fragment F0 + j KSN + ks), PXT MFMAs per fragment; `init(j)` sets
+    // tile j's accumulators up, `run(j, t, pr)` is one 8-channel run of tile j's epilogue: the 2 PXT runs of tile j - 1 are
+    // dealt out over the k-slices of tile j (`pipelined`; false = every epilogue behind the loop, as for blocks whose
+    // epilogue loads from memory), `before_last()` runs between the last MFMA and the last tile's (exposed) epilogue
+    auto contract_cm = [&](auto mt_tag, auto ks_tag, auto f0_tag, auto&& frag, auto& acc, auto&& init, auto&& run, bool pipelined,
+                           auto&& before_last) {
+        constexpr int MT = decltype(mt_tag)::value;
+        constexpr int KSN = decltype(ks_tag)::value;
+        constexpr int F0 = decltype(f0_tag)::value;
+        constexpr int NRUN = 2 * PXT;
+        static_assert(KSN >= 2 * NRUN, "one run of the previous tile's epilogue per KSN / NRUN k-slices");
+        static_for<0, MT>([&](auto j_tag) {
+            constexpr int j = decltype(j_tag)::value;
+            init(j_tag);
+            half8 b[2][PXT];
+#pragma unroll
+            for (int t = 0; t < PXT; ++t) b[0][t] = frag(t, 0);
+            static_for<0, KSN>([&](auto kt) {
+                constexpr int ks = decltype(kt)::value;
+                if constexpr (ks + 1 < KSN) {
+#pragma unroll
+                    for (int t = 0; t < PXT; ++t) b[(ks + 1) & 1][t] = frag(t, ks + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const half8 a = ring[(F0 + j * KSN + ks) % RING];
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks & 1][t], acc[j][t], 0, 0, 0);
+                if constexpr (j > 0 && (ks % (KSN / NRUN)) == 1 && ks / (KSN / NRUN) < NRUN) {
+                    constexpr int r = ks / (KSN / NRUN);
+                    if (pipelined) run(std::integral_constant<int, j - 1>{}, std::integral_constant<int, r / 2>{}, std::integral_constant<int, r % 2>{});
+                }
+                issue(std::integral_constant<int, F0 + j * KSN + ks + RING>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        before_last();
+        static_for<0, MT>([&](auto j_tag) {
+            constexpr int j = decltype(j_tag)::value;
+            if (j == MT - 1 || !pipelined) {
+                static_for<0, NRUN>([&](auto r_tag) {
+                    constexpr int r = decltype(r_tag)::value;
+                    run(j_tag, std::integral_constant<int, r / 2>{}, std::integral_constant<int, r % 2>{});
+                });
+            }
+        });
+    };
+    auto nothing = [] {};
 
     // whole rows of an LDS tile -> memory, 16 bytes per lane, consecutive lanes = consecutive chunks of a row
     auto copy_out = [&](auto chunks_tag, const char* buf, int pitch, half_t* dst, int ld) {
@@ -397,30 +496,49 @@ dcb_nsplit_kernel(const NsParams p)
     // invariants the compiler hoists EVERY derived address out of the loop (one register pair per weight fragment,
     // one register per LDS fragment: 1 000+ values) and spills them all (measured: 1 023 spilled registers).
     asm volatile("" : "+v"(wsm), "+v"(wsn), "+v"(tab), "+v"(s0), "+v"(rowA), "+v"(rowB), "+v"(hi4), "+v"(tidv), "+v"(pxv), "+v"(hiv));
+    if constexpr (ADDR8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa8[i] = rowA + ((32 * i) ^ s0);
+            fb8[i] = rowB + ((32 * i) ^ s0);
+        }
+    }
     const int next_tile = tile + static_cast<int>(gridDim.x);
     const bool has_next = next_tile < ntiles;
     // ================================================================ dc.3: y1 = W3 t2 + b3' + x   (A -> B)
     {
         float16v acc[MT_C][PXT];
+        auto dc3_run = [&](auto j_tag, auto t_tag, auto pr_tag) {
+            constexpr int j = decltype(j_tag)::value, t = decltype(t_tag)::value, pr = decltype(pr_tag)::value;
+            float v[8];
+            runs_of(acc[j][t], pr, v);
+            half8 o;
 #pragma unroll
-        for (int j = 0; j < MT_C; ++j)
+            for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[j][t][pr][e]));
+            *run_b(t, 32 * (wave * MT_C + j) + 16 * pr) = o;
+        };
+        if constexpr (CHMAJOR) {
+            contract_cm(TagMTC{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc,
+                        [&](auto j_tag) {
+                            constexpr int j = decltype(j_tag)::value;
 #pragma unroll
-            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT_C + j));
-        contract(TagMTC{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc, no_piece);
-        stamp();
+                            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT_C + j));
+                        },
+                        dc3_run, true, [&] { stamp(); });
+        } else {
 #pragma unroll
-        for (int j = 0; j < MT_C; ++j)
+            for (int j = 0; j < MT_C; ++j)
 #pragma unroll
-            for (int t = 0; t < PXT; ++t)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    float v[8];
-                    runs_of(acc[j][t], pr, v);
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[j][t][pr][e]));
-                    *run_b(t, 32 * (wave * MT_C + j) + 16 * pr) = o;
-                }
+                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT_C + j));
+            contract(TagMTC{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc, no_piece);
+            stamp();
+            static_for<0, MT_C>([&](auto j_tag) {
+                static_for<0, PXT>([&](auto t_tag) {
+                    dc3_run(j_tag, t_tag, std::integral_constant<int, 0>{});
+                    dc3_run(j_tag, t_tag, std::integral_constant<int, 1>{});
+                });
+            });
+        }
     }
     __syncthreads();            // y1 complete in B; every wave is done with t2 in A
     stamp();
@@ -552,7 +670,11 @@ dcb_nsplit_kernel(const NsParams p)
                 stamp();
             }
         });
-        // the last pass's epilogue has nothing to hide behind
+        // the last pass's epilogue has nothing to hide behind (and needs no weights: the next tile's x goes out in front of it)
+        if constexpr (XEARLY == 1) {
+            load_x(next_tile * PX);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         epilogue_serial(accs[PIPE ? (NP - 1) & 1 : 0], wave * CI + (NP - 1) * (32 * TP));
         stamp();
     }
@@ -561,57 +683,74 @@ dcb_nsplit_kernel(const NsParams p)
     // ================================================================ ffn.2: y = (W2 t + b2 + y1 [+ x]) [* q] -> fp16 [* q2]   (A -> B in place of y1)
     {
         float16v acc[MT_C][PXT];
+        auto ffn2_run = [&](auto j_tag, auto t_tag, auto pr_tag) {
+            constexpr int j = decltype(j_tag)::value, t = decltype(t_tag)::value, pr = decltype(pr_tag)::value;
+            const int ch = 32 * (wave * MT_C + j) + 16 * pr;          // + 8 hi
+            float v[8];
+            runs_of(acc[j][t], pr, v);
+            half8* const slot = run_b(t, ch);
+            const half8 y1 = *slot;
 #pragma unroll
-        for (int j = 0; j < MT_C; ++j)
+            for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(y1[e]);
+            if (p.shortcut) {
+                const int m = min(m0 + 32 * t + px, p.M - 1);
+                const half8 r8 = *reinterpret_cast<const half8*>(p.x + static_cast<size_t>(m) * p.ldx + ch + 8 * hi);
 #pragma unroll
-            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT_C + j));
-        contract(TagMTC{}, KsI{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, frag_a, acc, no_piece);
-        stamp();
+                for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
+            }
+            if (p.q != nullptr) {
+                const half8 q8 = *reinterpret_cast<const half8*>(lq + ch + 8 * hi);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
+            }
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+            if (p.q2 != nullptr) {
+                const half8 q8 = *reinterpret_cast<const half8*>(lq2 + ch + 8 * hi);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
+            }
+            if constexpr (NEXT || !DIRECT_Y) *slot = o;          // dc.0's operand
+            if constexpr (DIRECT_Y) {
+                // 16 bytes per lane straight from the registers (half-waves pair up to 32-byte pieces of a row)
+                const int m = m0 + 32 * t + pxv;
+                if (m < p.M) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
+            }
+        };
         // the next tile's transfers (see the loop head): t is dead once every wave is behind its last ffn.2 MFMA
-        __syncthreads();
-        if (has_next) dma_tile(ChI{}, p.t2, p.ldt, 0, next_tile * PX);
-        // (unconditional - rows are clamped to the picture -: a conditional load keeps the old values alive)
-        if constexpr (!NEXT) load_x(next_tile * PX);
-        __builtin_amdgcn_sched_barrier(0);
+        auto behind_mfmas = [&] {
+            stamp();
+            __syncthreads();
+            if (has_next) dma_tile(ChI{}, p.t2, p.ldt, 0, next_tile * PX);
+            // (unconditional - rows are clamped to the picture -: a conditional load keeps the old values alive)
+            if constexpr ((!NEXT && XEARLY == 0) || XEARLY == 2) load_x(next_tile * PX);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (CHMAJOR) {
+            // (blocks with the block-level shortcut load x inside the epilogue: a load from memory among the weight
+            // fragments holds up every fragment behind it - their epilogues stay behind the contraction)
+            contract_cm(TagMTC{}, KsI{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, frag_a, acc,
+                        [&](auto j_tag) {
+                            constexpr int j = decltype(j_tag)::value;
 #pragma unroll
-        for (int j = 0; j < MT_C; ++j)
+                            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT_C + j));
+                        },
+                        ffn2_run, p.shortcut == 0, behind_mfmas);
+        } else {
 #pragma unroll
-            for (int t = 0; t < PXT; ++t)
+            for (int j = 0; j < MT_C; ++j)
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int ch = 32 * (wave * MT_C + j) + 16 * pr;          // + 8 hi
-                    float v[8];
-                    runs_of(acc[j][t], pr, v);
-                    half8* const slot = run_b(t, ch);
-                    const half8 y1 = *slot;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(y1[e]);
-                    if (p.shortcut) {
-                        const int m = min(m0 + 32 * t + px, p.M - 1);
-                        const half8 r8 = *reinterpret_cast<const half8*>(p.x + static_cast<size_t>(m) * p.ldx + ch + 8 * hi);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
-                    }
-                    if (p.q != nullptr) {
-                        const half8 q8 = *reinterpret_cast<const half8*>(lq + ch + 8 * hi);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
-                    }
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-                    if (p.q2 != nullptr) {
-                        const half8 q8 = *reinterpret_cast<const half8*>(lq2 + ch + 8 * hi);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
-                    }
-                    if constexpr (NEXT || !DIRECT_Y) *slot = o;          // dc.0's operand
-                    if constexpr (DIRECT_Y) {
-                        // 16 bytes per lane straight from the registers (half-waves pair up to 32-byte pieces of a row)
-                        const int m = m0 + 32 * t + pxv;
-                        if (m < p.M) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
-                    }
-                }
+                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT_C + j));
+            contract(TagMTC{}, KsI{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, frag_a, acc, no_piece);
+            behind_mfmas();
+            static_for<0, MT_C>([&](auto j_tag) {
+                static_for<0, PXT>([&](auto t_tag) {
+                    ffn2_run(j_tag, t_tag, std::integral_constant<int, 0>{});
+                    ffn2_run(j_tag, t_tag, std::integral_constant<int, 1>{});
+                });
+            });
+        }
     }
     if constexpr (NEXT || !DIRECT_Y) __syncthreads();            // y complete in B; every wave is done with t in A
     stamp();
@@ -621,47 +760,63 @@ dcb_nsplit_kernel(const NsParams p)
     // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')   (B -> B)
     if constexpr (NEXT) {
         float16v acc[MT_I][PXT];
+        auto dc0_run = [&](auto j_tag, auto t_tag, auto pr_tag) {
+            constexpr int j = decltype(j_tag)::value, t = decltype(t_tag)::value, pr = decltype(pr_tag)::value;
+            float v[8];
+            runs_of(acc[j][t], pr, v);
+            float4v c[8];
 #pragma unroll
-        for (int j = 0; j < MT_I; ++j)
+            for (int e = 0; e < 8; ++e) {
+                const float4 r = wsilu_row_lds<R, true>(v[e], tab);
+                c[e] = float4v{r.x, r.y, r.z, r.w};
+            }
+            half8 o;
 #pragma unroll
-            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, 32 * (wave * MT_I + j));
-        contract(TagMTI{}, KsC{}, std::integral_constant<int, G::F_MAIN>{}, frag_b, acc, no_piece);
-        // the ring is empty: the first fragments of the next tile go out now and arrive under the epilogue below
-        if (has_next) {
+            for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], make_float4(c[e][0], c[e][1], c[e][2], c[e][3])));
+            if constexpr (DIRECT_T1) {
+                const int m = m0 + 32 * t + pxv;
+                if (m < p.M) store_line(p.t1n + static_cast<size_t>(m) * p.ldt1 + 32 * (wave * MT_I + j) + 16 * pr + 8 * hiv, o);
+            } else {
+                // staged with B's pitch, the CI channels in the first CI / 8 chunks of a row
+                *run_b(t, 32 * (wave * MT_I + j) + 16 * pr) = o;
+            }
+        };
+        auto behind_mfmas = [&] {
+            // the ring is empty: the first fragments of the next tile go out now and arrive under the epilogue below
+            if (has_next) {
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, RING>([&](auto i) { issue(i); });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stamp();
+            if constexpr (!DIRECT_T1) __syncthreads();        // every wave is done with y as an operand (and with copying it out): B becomes the staging area
+            // x of the next tile: a second burst of its own (all CUs ask at the same moment: 12 MB at 1080p), under this epilogue
+            if constexpr (XEARLY == 0) load_x(next_tile * PX);
             __builtin_amdgcn_sched_barrier(0);
-            static_for<0, RING>([&](auto i) { issue(i); });
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (CHMAJOR) {
+            // (staged outputs - NS_DIRECT bit 0 off - overwrite the operand tile: no epilogue before every wave's last MFMA)
+            contract_cm(TagMTI{}, KsC{}, std::integral_constant<int, G::F_MAIN>{}, frag_b, acc,
+                        [&](auto j_tag) {
+                            constexpr int j = decltype(j_tag)::value;
+#pragma unroll
+                            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, 32 * (wave * MT_I + j));
+                        },
+                        dc0_run, DIRECT_T1, behind_mfmas);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MT_I; ++j)
+#pragma unroll
+                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, 32 * (wave * MT_I + j));
+            contract(TagMTI{}, KsC{}, std::integral_constant<int, G::F_MAIN>{}, frag_b, acc, no_piece);
+            behind_mfmas();
+            static_for<0, MT_I>([&](auto j_tag) {
+                static_for<0, PXT>([&](auto t_tag) {
+                    dc0_run(j_tag, t_tag, std::integral_constant<int, 0>{});
+                    dc0_run(j_tag, t_tag, std::integral_constant<int, 1>{});
+                });
+            });
         }
-        stamp();
-        if constexpr (!DIRECT_T1) __syncthreads();        // every wave is done with y as an operand (and with copying it out): B becomes the staging area
-        // x of the next tile: a second burst of its own (all CUs ask at the same moment: 12 MB at 1080p), under this epilogue
-        load_x(next_tile * PX);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < MT_I; ++j)
-#pragma unroll
-            for (int t = 0; t < PXT; ++t)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    float v[8];
-                    runs_of(acc[j][t], pr, v);
-                    float4v c[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float4 r = wsilu_row_lds<R, true>(v[e], tab);
-                        c[e] = float4v{r.x, r.y, r.z, r.w};
-                    }
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], make_float4(c[e][0], c[e][1], c[e][2], c[e][3])));
-                    if constexpr (DIRECT_T1) {
-                        const int m = m0 + 32 * t + pxv;
-                        if (m < p.M) store_line(p.t1n + static_cast<size_t>(m) * p.ldt1 + 32 * (wave * MT_I + j) + 16 * pr + 8 * hiv, o);
-                    } else {
-                        // staged with B's pitch, the CI channels in the first CI / 8 chunks of a row
-                        *run_b(t, 32 * (wave * MT_I + j) + 16 * pr) = o;
-                    }
-                }
         if constexpr (!DIRECT_T1) __syncthreads();
         stamp();
         if constexpr (!DIRECT_T1) copy_out(ChI{}, bufB, PITCH_C, p.t1n, p.ldt1);
@@ -681,6 +836,8 @@ dcb_nsplit_kernel(const NsParams p)
     tile = next_tile;
     m0 = tile * PX;
     }       // tiles
+    // stamp 31: the workgroup's last instruction (all tiles): cycles of the whole launch per workgroup -> effective clock
+    if (p.timeline != nullptr && tid == 0) p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 31] = static_cast<long long>(__builtin_readcyclecounter());
 }
 template <int C, int CI, int PXT>
 constexpr int smem_bytes()

@@ -604,7 +604,7 @@ bool dcb_tail_supported(int H, int W, int c, int cdc, int cffn)
     if (mode == 0 || H <= 0 || W <= 0 || !shape_ok(c, cdc, cffn)) return false;
     const int patches = ((H + PH - 1) / PH) * ((W + PW - 1) / PW);
     // the 128-wide blocks (LD's hyper networks at / 16 .. / 64: 72 patches and fewer) are pure launch latency either way:
-    // one launch instead of five (LD 1080p 313 -> 319 pictures/s, DCVC_DCB_TAIL=1 vs 2 in tools/r3_session19.sh)
+    // one launch instead of five (LD 1080p 313 -> 319 pictures/s, DCVC_DCB_TAIL=1 vs 2, A/B of round 3)
     return mode == 2 || patches >= 192 || c <= 128;
 }
 

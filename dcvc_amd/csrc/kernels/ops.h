@@ -99,6 +99,7 @@ struct DcbNsplitDesc {
     int pixels = 0, c = 0, ci = 0;
     bool shortcut = false;
 };
+int dcb_nsplit_waves();                                      // 8 (round 4) or 4 (DCVC_NSPLIT_WAVES=4: round 3's kernel, A/B)
 bool dcb_nsplit_shape(int c, int ci);                         // a shape the kernel is instantiated for
 bool dcb_nsplit_supported(int c, int cdc, int cffn);          // DCVC_NSPLIT: 0 = off, 1 = full-width blocks only (A/B)
 size_t dcb_nsplit_main_halves(int c, int ci);

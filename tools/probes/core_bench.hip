@@ -223,7 +223,14 @@ int main(int argc, char** argv)
             static const char* names[13] = {"prologue", "dc.3 mfma", "x + dc.3 epi + bar", "ffn0.0 mfma", "ffn0.1 mfma | epi 0", "ffn0.2 mfma | epi 1", "epi 2",
                                              "bar + ffn.2 mfma", "epi + bar", "y out", "dc.0 mfma", "epi + bar", "t1n out"};
             printf("  nsplit timeline (median cycles over workgroups):");
-            const int nstamps = 10 + (CI >= 256 ? CI / 128 : CI / 64);     // see the stamp list in dcb_nsplit.hip
+            // number of intervals = stamps written by the first workgroup that ran - 1 (4-wave kernel: 10 + ffn.0 passes, see the
+            // stamp list in dcb_nsplit_kernel.h; 8-wave kernel: entry | prologue | dc.3 | one per ffn.0 pass | ffn.0 done | ffn.2 MFMAs
+            // | ffn.2 | dc.0 MFMAs | dc.0)
+            int nstamps = 0;
+            for (size_t w = 0; w < rows && nstamps == 0; ++w) {
+                if (h[w * 32] == 0) continue;
+                for (int i = 1; i < 32 && h[w * 32 + i] != 0; ++i) nstamps = i;
+            }
             for (int i = 0; i < nstamps; ++i) {
                 std::vector<float> d;
                 for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && h[w * 32 + i + 1] != 0) d.push_back(static_cast<float>(h[w * 32 + i + 1] - h[w * 32 + i]));
@@ -234,8 +241,16 @@ int main(int argc, char** argv)
             for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && (t0 == 0 || h[w * 32] < t0)) t0 = h[w * 32];
             for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0) { tot.push_back(static_cast<float>(h[w * 32 + nstamps] - h[w * 32])); start.push_back(static_cast<float>(h[w * 32] - t0)); }
             std::sort(start.begin(), start.end());
-            printf(" total %.0f | workgroups %zu, start of the median / last workgroup %.0f / %.0f\n", median(tot), tot.size(),
+            // stamp 31 (round 4) = the workgroup's last instruction: whole-launch cycles per workgroup; with the launch's wall time
+            // (us_ns_next) the effective shader clock
+            std::vector<float> whole;
+            long long tend = 0;
+            for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && h[w * 32 + 31] != 0) { whole.push_back(static_cast<float>(h[w * 32 + 31] - h[w * 32])); tend = std::max(tend, h[w * 32 + 31]); }
+            printf(" total %.0f | workgroups %zu, start of the median / last workgroup %.0f / %.0f", median(tot), tot.size(),
                    start.empty() ? 0.f : start[start.size() / 2], start.empty() ? 0.f : start.back());
+            if (!whole.empty()) printf(" | whole launch: median workgroup %.0f cycles, first start to last end %.0f cycles = %.2f GHz at %.1f us",
+                                       median(whole), static_cast<double>(tend - t0), static_cast<double>(tend - t0) / median(l.us_ns_next) / 1e3, median(l.us_ns_next));
+            printf("\n");
         }
         if (l.tl && has_core) {
             long long* tl = nullptr;
