@@ -369,8 +369,8 @@ def cpu_baseline(cpu_net):
     }
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
-KERNEL_SOURCES = ("dcb_nsplit_kernel.h", "dcb_nsplit.hip", "dcb_core.hip", "conv_gemm.hip", "dcb_tail.hip", "ffn_fused.hip", "dwconv.hip",
+TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
+KERNEL_SOURCES = ("dcb_nsplit8_kernel.h", "dcb_nsplit_kernel.h", "dcb_nsplit.hip", "conv_gemm.hip", "dcb_tail.hip", "ffn_fused.hip", "dwconv.hip",
                   "arith.h")
 
 
@@ -399,7 +399,8 @@ def pmc_traffic(kernel):
         return None, "no PMC pass on file (%s)" % type(e).__name__
 
 
-KERNEL_NAMES = {0: "conv_gemm_kernel", 1: "dcb_core_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "dcb_nsplit_kernel"}
+KERNEL_NAMES = {0: "conv_gemm_kernel", 1: "dcb_core_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "dcb_nsplit_kernel",
+                5: "dcb_nsplit8_kernel"}
 
 
 def roofline(work, n=len(QPS)):
@@ -454,7 +455,7 @@ def roofline(work, n=len(QPS)):
     kernels = []
     for f, name in KERNEL_NAMES.items():
         sel = family == f
-        if f == 4:
+        if f in (4, 5):
             # one entry per shape of the N-split block kernel: <C, CI, pixels per workgroup> follows from (N, K, M): K = 7 CI
             # with the next block's dc.0 inside the launch, 6 CI without (dcb_nsplit_kernel.h launch())
             inner = {k * ci: ci for ci in (128, 256, 384, 512, 768) for k in (6, 7)}

@@ -22,18 +22,14 @@ __global__ void pack_main_kernel(const half_t* w3, const half_t* w0, const half_
     const int wave = static_cast<int>((u >> 6) / F_MAIN);
     const half_t* w;
     int n0, ks, K;
-    // (NS_CHMAJOR: dc.3 / ffn.2 / dc.0 consume their fragments channel tile by channel tile - tile j's KS slices, then
-    // tile j + 1's -, otherwise k-slice by k-slice over all tiles; ffn.0 always k-slice by k-slice within a pass)
     if (f < F_DC3) {                                  // dc.3 [C][CI]
-        if (CHMAJOR) { ks = f % KS_I; n0 = 32 * (wave * MT_C + f / KS_I); } else { ks = f / MT_C; n0 = 32 * (wave * MT_C + f % MT_C); }
-        w = w3; K = CI;
+        ks = f / MT_C; n0 = 32 * (wave * MT_C + f % MT_C); w = w3; K = CI;
     } else if (f < F_DC3 + F_FFN0) {                  // ffn.0 [4 CI][C]: the wave's CI channels in passes of TP tiles
         const int g = f - F_DC3, pass = g / (TP * KS_C), r = g % (TP * KS_C);
         ks = r / TP; n0 = wave * CI + pass * 32 * TP + 32 * (r % TP); w = w0; K = C;
     } else {                                          // ffn.2 [C][CI]
         const int g = f - F_DC3 - F_FFN0;
-        if (CHMAJOR) { ks = g % KS_I; n0 = 32 * (wave * MT_C + g / KS_I); } else { ks = g / MT_C; n0 = 32 * (wave * MT_C + g % MT_C); }
-        w = w2; K = CI;
+        ks = g / MT_C; n0 = 32 * (wave * MT_C + g % MT_C); w = w2; K = CI;
     }
     out[u] = *reinterpret_cast<const half8*>(w + static_cast<size_t>(n0 + (lane & 31)) * K + 16 * ks + 8 * (lane >> 5));
 }
@@ -46,7 +42,7 @@ __global__ void pack_dc0_kernel(const half_t* w1, int C, int CI, half8* out)    
     const int lane = static_cast<int>(u & 63);
     const int f = static_cast<int>((u >> 6) % F);
     const int wave = static_cast<int>((u >> 6) / F);
-    const int ks = CHMAJOR ? f % KS_C : f / MT_I, n0 = 32 * (wave * MT_I + (CHMAJOR ? f / KS_C : f % MT_I));
+    const int ks = f / MT_I, n0 = 32 * (wave * MT_I + f % MT_I);
     out[u] = *reinterpret_cast<const half8*>(w1 + static_cast<size_t>(n0 + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5));
 }
 

@@ -531,7 +531,7 @@ void launch8(const NsParams& p, hipStream_t stream)
     const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;
     const int kflop = (NEXT ? 7 : 6) * CI;
-    if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x40000000, 0.f}, &ev0, &ev1)) {
+    if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x50000000, 0.f}, &ev0, &ev1)) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, ev0, ev1, 0, p);
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, p);

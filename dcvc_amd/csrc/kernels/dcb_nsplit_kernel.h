@@ -62,17 +62,10 @@ constexpr int NTHREADS = 256;
 #endif
 constexpr int RING_DEFAULT = NS_RING;    // weight fragments in flight per wave (4 registers each)
 // Round-4 switches (each bit-identical; defaults = what measured best, profiles/r04_core_bench_*.txt):
-//   NS_CHMAJOR  dc.3 / ffn.2 / dc.0 walk the wave's channel tiles ONE AFTER THE OTHER (each over all k-slices) instead of
-//               all tiles per k-slice: the epilogue of tile j - cut into 2 PXT runs - issues beside the MFMAs of tile
-//               j + 1, so only the LAST tile's epilogue (a third of it) is exposed, and the output stores spread over the
-//               phase instead of leaving in one burst. Changes the order of the packed weight stream (dcb_nsplit.hip).
 //   NS_XEARLY   where the next tile's x is requested: 0 = in front of dc.0's epilogue (round 3), 1 = in front of the last
 //               ffn.0 pass's (exposed) epilogue - one transfer burst per exposed epilogue: x | t2 + y | t1' -, 2 = with t2
 //               behind ffn.2's MFMAs (x + t2 + y | t1')
 //   NS_WAITLAST within a k-slice the LAST fragment of the slice feeds the first MFMAs: one counted wait per slice
-#ifndef NS_CHMAJOR
-#define NS_CHMAJOR 0
-#endif
 #ifndef NS_XEARLY
 #define NS_XEARLY 2
 #endif
@@ -89,7 +82,7 @@ constexpr int RING_DEFAULT = NS_RING;    // weight fragments in flight per wave 
 #ifndef NS_ADDR8
 #define NS_ADDR8 1
 #endif
-constexpr bool CHMAJOR = NS_CHMAJOR != 0, WAITLAST = NS_WAITLAST != 0;
+constexpr bool WAITLAST = NS_WAITLAST != 0;
 constexpr int XEARLY = NS_XEARLY;
 constexpr bool BUFLOAD = NS_BUFLOAD != 0, ADDR8 = NS_ADDR8 != 0;
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
@@ -423,53 +416,6 @@ dcb_nsplit_kernel(const NsParams p)
     using KsC = std::integral_constant<int, KS_C>;
     using KsI = std::integral_constant<int, KS_I>;
     auto no_piece = [](int) {};
-    // NS_CHMAJOR: MT channel tiles one after the other (fragment F0 + j KSN + ks), PXT MFMAs per fragment; `init(j)` sets
-    // tile j's accumulators up, `run(j, t, pr)` is one 8-channel run of tile j's epilogue: the 2 PXT runs of tile j - 1 are
-    // dealt out over the k-slices of tile j (`pipelined`; false = every epilogue behind the loop, as for blocks whose
-    // epilogue loads from memory), `before_last()` runs between the last MFMA and the last tile's (exposed) epilogue
-    auto contract_cm = [&](auto mt_tag, auto ks_tag, auto f0_tag, auto&& frag, auto& acc, auto&& init, auto&& run, bool pipelined,
-                           auto&& before_last) {
-        constexpr int MT = decltype(mt_tag)::value;
-        constexpr int KSN = decltype(ks_tag)::value;
-        constexpr int F0 = decltype(f0_tag)::value;
-        constexpr int NRUN = 2 * PXT;
-        static_assert(KSN >= 2 * NRUN, "one run of the previous tile's epilogue per KSN / NRUN k-slices");
-        static_for<0, MT>([&](auto j_tag) {
-            constexpr int j = decltype(j_tag)::value;
-            init(j_tag);
-            half8 b[2][PXT];
-#pragma unroll
-            for (int t = 0; t < PXT; ++t) b[0][t] = frag(t, 0);
-            static_for<0, KSN>([&](auto kt) {
-                constexpr int ks = decltype(kt)::value;
-                if constexpr (ks + 1 < KSN) {
-#pragma unroll
-                    for (int t = 0; t < PXT; ++t) b[(ks + 1) & 1][t] = frag(t, ks + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const half8 a = ring[(F0 + j * KSN + ks) % RING];
-#pragma unroll
-                for (int t = 0; t < PXT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks & 1][t], acc[j][t], 0, 0, 0);
-                if constexpr (j > 0 && (ks % (KSN / NRUN)) == 1 && ks / (KSN / NRUN) < NRUN) {
-                    constexpr int r = ks / (KSN / NRUN);
-                    if (pipelined) run(std::integral_constant<int, j - 1>{}, std::integral_constant<int, r / 2>{}, std::integral_constant<int, r % 2>{});
-                }
-                issue(std::integral_constant<int, F0 + j * KSN + ks + RING>{});
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        before_last();
-        static_for<0, MT>([&](auto j_tag) {
-            constexpr int j = decltype(j_tag)::value;
-            if (j == MT - 1 || !pipelined) {
-                static_for<0, NRUN>([&](auto r_tag) {
-                    constexpr int r = decltype(r_tag)::value;
-                    run(j_tag, std::integral_constant<int, r / 2>{}, std::integral_constant<int, r % 2>{});
-                });
-            }
-        });
-    };
-    auto nothing = [] {};
 
     // whole rows of an LDS tile -> memory, 16 bytes per lane, consecutive lanes = consecutive chunks of a row
     auto copy_out = [&](auto chunks_tag, const char* buf, int pitch, half_t* dst, int ld) {
@@ -517,28 +463,18 @@ dcb_nsplit_kernel(const NsParams p)
             for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] + static_cast<float>(xr[j][t][pr][e]));
             *run_b(t, 32 * (wave * MT_C + j) + 16 * pr) = o;
         };
-        if constexpr (CHMAJOR) {
-            contract_cm(TagMTC{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc,
-                        [&](auto j_tag) {
-                            constexpr int j = decltype(j_tag)::value;
 #pragma unroll
-                            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT_C + j));
-                        },
-                        dc3_run, true, [&] { stamp(); });
-        } else {
+        for (int j = 0; j < MT_C; ++j)
 #pragma unroll
-            for (int j = 0; j < MT_C; ++j)
-#pragma unroll
-                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT_C + j));
-            contract(TagMTC{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc, no_piece);
-            stamp();
-            static_for<0, MT_C>([&](auto j_tag) {
-                static_for<0, PXT>([&](auto t_tag) {
-                    dc3_run(j_tag, t_tag, std::integral_constant<int, 0>{});
-                    dc3_run(j_tag, t_tag, std::integral_constant<int, 1>{});
-                });
+            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb3, 32 * (wave * MT_C + j));
+        contract(TagMTC{}, KsI{}, std::integral_constant<int, 0>{}, frag_a, acc, no_piece);
+        stamp();
+        static_for<0, MT_C>([&](auto j_tag) {
+            static_for<0, PXT>([&](auto t_tag) {
+                dc3_run(j_tag, t_tag, std::integral_constant<int, 0>{});
+                dc3_run(j_tag, t_tag, std::integral_constant<int, 1>{});
             });
-        }
+        });
     }
     __syncthreads();            // y1 complete in B; every wave is done with t2 in A
     stamp();
@@ -727,30 +663,18 @@ dcb_nsplit_kernel(const NsParams p)
             if constexpr ((!NEXT && XEARLY == 0) || XEARLY == 2) load_x(next_tile * PX);
             __builtin_amdgcn_sched_barrier(0);
         };
-        if constexpr (CHMAJOR) {
-            // (blocks with the block-level shortcut load x inside the epilogue: a load from memory among the weight
-            // fragments holds up every fragment behind it - their epilogues stay behind the contraction)
-            contract_cm(TagMTC{}, KsI{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, frag_a, acc,
-                        [&](auto j_tag) {
-                            constexpr int j = decltype(j_tag)::value;
 #pragma unroll
-                            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT_C + j));
-                        },
-                        ffn2_run, p.shortcut == 0, behind_mfmas);
-        } else {
+        for (int j = 0; j < MT_C; ++j)
 #pragma unroll
-            for (int j = 0; j < MT_C; ++j)
-#pragma unroll
-                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT_C + j));
-            contract(TagMTC{}, KsI{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, frag_a, acc, no_piece);
-            behind_mfmas();
-            static_for<0, MT_C>([&](auto j_tag) {
-                static_for<0, PXT>([&](auto t_tag) {
-                    ffn2_run(j_tag, t_tag, std::integral_constant<int, 0>{});
-                    ffn2_run(j_tag, t_tag, std::integral_constant<int, 1>{});
-                });
+            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb2, 32 * (wave * MT_C + j));
+        contract(TagMTC{}, KsI{}, std::integral_constant<int, G::F_DC3 + G::F_FFN0>{}, frag_a, acc, no_piece);
+        behind_mfmas();
+        static_for<0, MT_C>([&](auto j_tag) {
+            static_for<0, PXT>([&](auto t_tag) {
+                ffn2_run(j_tag, t_tag, std::integral_constant<int, 0>{});
+                ffn2_run(j_tag, t_tag, std::integral_constant<int, 1>{});
             });
-        }
+        });
     }
     if constexpr (NEXT || !DIRECT_Y) __syncthreads();            // y complete in B; every wave is done with t in A
     stamp();
@@ -794,29 +718,18 @@ dcb_nsplit_kernel(const NsParams p)
             if constexpr (XEARLY == 0) load_x(next_tile * PX);
             __builtin_amdgcn_sched_barrier(0);
         };
-        if constexpr (CHMAJOR) {
-            // (staged outputs - NS_DIRECT bit 0 off - overwrite the operand tile: no epilogue before every wave's last MFMA)
-            contract_cm(TagMTI{}, KsC{}, std::integral_constant<int, G::F_MAIN>{}, frag_b, acc,
-                        [&](auto j_tag) {
-                            constexpr int j = decltype(j_tag)::value;
 #pragma unroll
-                            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, 32 * (wave * MT_I + j));
-                        },
-                        dc0_run, DIRECT_T1, behind_mfmas);
-        } else {
+        for (int j = 0; j < MT_I; ++j)
 #pragma unroll
-            for (int j = 0; j < MT_I; ++j)
-#pragma unroll
-                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, 32 * (wave * MT_I + j));
-            contract(TagMTI{}, KsC{}, std::integral_constant<int, G::F_MAIN>{}, frag_b, acc, no_piece);
-            behind_mfmas();
-            static_for<0, MT_I>([&](auto j_tag) {
-                static_for<0, PXT>([&](auto t_tag) {
-                    dc0_run(j_tag, t_tag, std::integral_constant<int, 0>{});
-                    dc0_run(j_tag, t_tag, std::integral_constant<int, 1>{});
-                });
+            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, 32 * (wave * MT_I + j));
+        contract(TagMTI{}, KsC{}, std::integral_constant<int, G::F_MAIN>{}, frag_b, acc, no_piece);
+        behind_mfmas();
+        static_for<0, MT_I>([&](auto j_tag) {
+            static_for<0, PXT>([&](auto t_tag) {
+                dc0_run(j_tag, t_tag, std::integral_constant<int, 0>{});
+                dc0_run(j_tag, t_tag, std::integral_constant<int, 1>{});
             });
-        }
+        });
         if constexpr (!DIRECT_T1) __syncthreads();
         stamp();
         if constexpr (!DIRECT_T1) copy_out(ChI{}, bufB, PITCH_C, p.t1n, p.ldt1);

@@ -480,6 +480,16 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
 
 
+def _has_dcb_core(ops):
+    """the default build carries a stand-in for round 2's dcb_core (kernels/dcb_core_off.hip): its entry point reports so"""
+    from dcvc_amd import _lib
+    from gpu_util import stream
+    rc = ops.dcb_core(None, 0, None, 0, None, None, None, None, None, None, None, None, None, None, None, 0, None, 0, 1, 384, 0, stream())
+    if rc >= 0:
+        return True
+    return "not part of this build" not in _lib.lib().dcvc_last_error().decode("utf-8", "replace")
+
+
 @pytest.mark.parametrize("P,shortcut,quant,q2,nxt,inplace", [
     (128, False, False, False, False, False),       # one workgroup
     (300, False, False, False, True, True),         # ragged last workgroup, in place, next dc.0 fused
@@ -495,6 +505,8 @@ def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inpla
     residuals, quant) (-> conv1x1(dc.0, wsilu)), bit for bit; those launches are checked against
     the oracle above."""
     from gpu_util import call, ptr, stream
+    if not _has_dcb_core(ops):
+        pytest.skip("dcb_core (round 2's block kernel) is built on request only: DCVC_EXTRA_DEFS=-DDCVC_WITH_DCB_CORE")
     dev, C = "cuda", 384
     ldx = C + 64
     xbuf = _rand((P, ldx), 1.0, 301).to(dev)
@@ -632,7 +644,7 @@ def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, n
         assert (t1[:, CI:] == 7.0).all()
     else:
         assert (t1 == 7.0).all()
-    if C == 384:
+    if C == 384 and _has_dcb_core(ops):
         y2, t12 = run(ops.dcb_core)
         assert torch.equal(y2, ybuf) and torch.equal(t12, t1)
 

@@ -13,8 +13,8 @@ from collections import defaultdict
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 FAMILIES = ("dcb_core_kernel", "conv_gemm_kernel", "dwconv3x3_kernel", "dcb_tail_kernel", "ffn_fused_kernel")
-NSPLIT = re.compile(r"dcb_nsplit_kernel<(\d+), (\d+), (\d+), (true|false)>")
-NSPLIT_MANGLED = re.compile(r"dcb_nsplit_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E")
+NSPLIT = re.compile(r"dcb_nsplit(8?)_kernel<(\d+), (\d+), (\d+), (true|false)>")
+NSPLIT_MANGLED = re.compile(r"dcb_nsplit(8?)_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E")
 
 
 def family(name):
@@ -22,7 +22,7 @@ def family(name):
     (launches with and without the next block's dc.0 together), the others by name"""
     m = NSPLIT.search(name) or NSPLIT_MANGLED.search(name)
     if m:
-        return "dcb_nsplit_kernel<%s, %s, %d px>" % (m.group(1), m.group(2), 32 * int(m.group(3)))
+        return "dcb_nsplit%s_kernel<%s, %s, %d px>" % (m.group(1), m.group(2), m.group(3), 32 * int(m.group(4)))
     for f in FAMILIES:
         if f in name:
             return f

@@ -45,6 +45,7 @@ struct Lib {
     ns_fn ns = nullptr;            // dcvc_dcb_nsplit (+ the inner width), round 3
     nspack_fn ns_pack = nullptr;   // round 4: dcvc_dcb_nsplit packs per call; the handle form is what gets timed
     nspacked_fn ns_packed = nullptr;
+    bool has_core = false;         // round 2's dcb_core is in the library (since round 4 only in -DDCVC_WITH_DCB_CORE builds) and the shape is its
     void* ns_handle = nullptr;
     conv_fn conv = nullptr;
     dw_fn dw = nullptr;
@@ -92,7 +93,7 @@ int main(int argc, char** argv)
         else { Lib l; l.path = argv[i]; libs.push_back(l); }
     }
     if (CI == 0) CI = C;
-    const bool has_core = C == 384 && CI == 384;
+    const bool core_shape = C == 384 && CI == 384;
     if (libs.empty()) { fprintf(stderr, "usage: core_bench [-p pixels] [-r rounds] [-n launches] [-c block width] [-i inner width] lib.so ...\n"); return 2; }
     for (auto& l : libs) {
         l.h = dlopen(l.path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -134,6 +135,11 @@ int main(int argc, char** argv)
         chk(l, l.core(t2, C, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, next ? w1 : nullptr, next ? b1 : nullptr, next ? t1 : nullptr, C,
                       y, C, P, C, 0, st), "dcb_core");
     };
+    for (auto& l : libs) {
+        // a library built without dcb_core answers the call with an error: that build's reference result is the launch sequence
+        l.has_core = core_shape && l.core(t2, C, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, nullptr, nullptr, nullptr, C, y, C, P, C, 0, st) >= 0;
+    }
+    OK(hipStreamSynchronize(st));
     auto nsplit = [&](Lib& l, bool next) {
         if (l.ns_pack && l.ns_packed) {
             if (!l.ns_handle) chk(l, l.ns_pack(w3, w0, w2, w1, C, CI, st, &l.ns_handle), "dcb_nsplit_pack");
@@ -163,7 +169,7 @@ int main(int argc, char** argv)
     };
     for (int r = 0; r < rounds; ++r) {
         for (auto& l : libs) {
-            if (has_core) {
+            if (l.has_core) {
                 l.us_core_next.push_back(timed([&] { core(l, true); }));
                 l.us_core.push_back(timed([&] { core(l, false); }));
             }
@@ -178,7 +184,7 @@ int main(int argc, char** argv)
     const double flop = 2.0 * P * 7 * C * CI;
     std::vector<uint16_t> hy(static_cast<size_t>(P) * C);
     for (auto& l : libs) {
-        if (has_core) core(l, true); else seq(l);      // the reference result: dcb_core where it exists, else the four launches
+        if (l.has_core) core(l, true); else seq(l);      // the reference result: dcb_core where it exists, else the four launches
         OK(hipStreamSynchronize(st));
         OK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost));
         uint64_t sum = 0;
@@ -248,11 +254,16 @@ int main(int argc, char** argv)
             for (size_t w = 0; w < rows; ++w) if (h[w * 32] != 0 && h[w * 32 + 31] != 0) { whole.push_back(static_cast<float>(h[w * 32 + 31] - h[w * 32])); tend = std::max(tend, h[w * 32 + 31]); }
             printf(" total %.0f | workgroups %zu, start of the median / last workgroup %.0f / %.0f", median(tot), tot.size(),
                    start.empty() ? 0.f : start[start.size() / 2], start.empty() ? 0.f : start.back());
-            if (!whole.empty()) printf(" | whole launch: median workgroup %.0f cycles, first start to last end %.0f cycles = %.2f GHz at %.1f us",
-                                       median(whole), static_cast<double>(tend - t0), static_cast<double>(tend - t0) / median(l.us_ns_next) / 1e3, median(l.us_ns_next));
+            // (the counters of different XCDs are not aligned: only differences inside one workgroup mean anything)
+            if (!whole.empty()) {
+                std::sort(whole.begin(), whole.end());
+                printf(" | whole launch, cycles per workgroup: min %.0f, median %.0f, p90 %.0f, max %.0f; max / wall time %.1f us = %.2f GHz",
+                       whole.front(), whole[whole.size() / 2], whole[whole.size() * 9 / 10], whole.back(), median(l.us_ns_next),
+                       whole.back() / median(l.us_ns_next) / 1e3);
+            }
             printf("\n");
         }
-        if (l.tl && has_core) {
+        if (l.tl && l.has_core) {
             long long* tl = nullptr;
             const size_t rows = 1024;
             OK(hipMalloc(&tl, rows * 64 * 8));

@@ -1,0 +1,59 @@
+#!/bin/bash
+# round 4, closing session (ONE gpurun call): box identity, PMC traffic of the bench's kernels, the whole GPU suite,
+# smoke(), the default bench line, kernel-trace summaries per workload, the block bench for every shape (8-wave kernel and
+# its 4-wave A/B partner in one process), clock / power evidence (GRBM_GUI_ACTIVE per launch, rocm-smi samples during a
+# sustained run). Outputs under gpurun_out/r04/; the ones quoted in DESIGN.md are copied to profiles/r04_*.
+set -x
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r04
+mkdir -p $O
+B=tools/_bin
+L=dcvc_amd/libdcvc_amd.so
+{ hostname; lscpu | grep -i "model name"; rocm-smi --showuniqueid --showserial --showproductname 2>/dev/null | grep -v "^=\|^$"; cat .git_head 2>/dev/null; } > $O/box.txt 2>&1
+# a throttled box (seen once in round 3: everything 1.7x slower) is not worth the GPU minutes: check the block kernel first
+us=$(timeout 120 $B/core_bench -r 2 -n 10 $L | grep "dcb_nsplit + next" | head -1 | awk '{print $6}')
+echo "block kernel: $us us" | tee -a $O/box.txt
+if [ -z "$us" ] || awk -v u="$us" 'BEGIN { exit !(u > 100) }'; then echo "SLOW BOX - stopping"; exit 7; fi
+BENCH="python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --no-uhd --min-seconds 0"
+cd /tmp
+timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc4/bench_fetch -o bench_fetch -- $BENCH > $O/pmc_bench_fetch.log 2>&1
+timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc4/bench_write -o bench_write -- $BENCH > $O/pmc_bench_write.log 2>&1
+cd $R
+python tools/hbm_traffic.py /tmp/pmc4/bench_fetch /tmp/pmc4/bench_write $O/r04_hbm_traffic.json "$(cat .git_head 2>/dev/null)" | grep -A5 "nsplit8_kernel<384"
+cp $O/r04_hbm_traffic.json profiles/r04_hbm_traffic.json
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/r04_test_gpu.log
+tail -4 $O/r04_test_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.log
+timeout 900 python bench.py > $O/r04_bench_line.json 2> $O/r04_bench.err
+tail -1 $O/r04_bench_line.json | cut -c1-600
+tail -2 $O/r04_bench.err
+# block bench, every shape: this build (8 waves) and the same sources dispatching to the 4-wave kernel (tools/_bin/w4.so =
+# tools/build_variant.sh w4 -DNS_WAVES_DEFAULT=4)
+V=""; [ -f $B/w4.so ] && V=$B/w4.so
+{ for sh in "384 384 32640" "512 256 32640" "512 512 32640" "256 256 32640" "256 128 32640" "512 512 8160" "768 768 8160" "384 384 129600"; do
+    set -- $sh; echo "=== C $1 CI $2 pixels $3"; timeout 200 $B/core_bench -r 3 -n 20 -c $1 -i $2 -p $3 $L $V; done; } > $O/r04_core_bench_shapes.txt 2>&1
+grep "dcb_nsplit + next" $O/r04_core_bench_shapes.txt | cut -c1-120
+cd /tmp
+for w in intra hts htl ld; do
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof4_$w -o t -- python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-uhd --no-extras --no-roofline --min-seconds 0 > $O/r04_prof_$w.log 2>&1
+  find /tmp/prof4_$w -name "t_kernel_stats.csv" -exec cp {} $O/r04_${w}_kernel_stats.csv \;
+  head -4 $O/r04_${w}_kernel_stats.csv | cut -c1-200
+done
+# clocks: GUI-active cycles per launch (summed over the 8 XCDs) next to the launch durations of the same command
+for v in $L $V; do
+  n=$(basename $v .so)
+  timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc4/clk_$n -o clk -- $R/$B/core_bench -r 2 -n 10 $R/$v > $O/clk_$n.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmc4/dur_$n -o dur -- $R/$B/core_bench -r 2 -n 10 $R/$v > $O/dur_$n.log 2>&1
+  find /tmp/pmc4/dur_$n -name "dur_kernel_stats.csv" -exec cp {} $O/r04_block_${n}_kernel_stats.csv \;
+done
+cd $R
+python tools/pmc_summary.py /tmp/pmc4 2>/dev/null | grep -i "clk\|nsplit" | cut -c1-260 > $O/r04_block_clocks.txt
+cat $O/r04_block_clocks.txt
+# power / clock samples during a sustained intra run
+( for i in $(seq 1 40); do echo "== $(date +%s.%N)"; rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power \(W\)|sclk"; sleep 0.25; done ) > $O/r04_smi_during_bench.txt 2>&1 &
+SMI=$!
+sleep 1
+timeout 600 python bench.py --steps 100 --min-seconds 8 --no-extras --no-cpu-baseline --no-roofline > $O/r04_bench_sustained.json 2> /dev/null
+wait $SMI
+grep -E "Power \(W\)" $O/r04_smi_during_bench.txt | sort | uniq -c | sort -rn | head -5
