@@ -107,9 +107,10 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     const int cb_0 = wave * (32 * G::N0);
     // stamps (wave 0, first tile): 0 entry | 1 constants + first t2 in LDS | 2 dc.3 done (barrier) | one per ffn.0 pass |
     // ffn.0 done (barrier) | ffn.2 MFMAs | ffn.2 done | dc.0 MFMAs | dc.0 done
+    const long long rt0 = static_cast<long long>(__builtin_amdgcn_s_memrealtime());
     int stamp_no = 0;
     auto stamp = [&]() {
-        if (p.timeline != nullptr && tid == 0 && stamp_no < 32 && tile == static_cast<int>(blockIdx.x)) {
+        if (p.timeline != nullptr && tid == 0 && stamp_no < 29 && tile == static_cast<int>(blockIdx.x)) {
             p.timeline[static_cast<size_t>(blockIdx.x) * 32 + stamp_no] = static_cast<long long>(__builtin_readcyclecounter());
         }
         ++stamp_no;
@@ -484,8 +485,13 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     tile = next_tile;
     m0 = tile * PX;
     }       // tiles
-    // stamp 31: the workgroup's last instruction (all tiles): cycles of the whole launch per workgroup -> effective clock
-    if (p.timeline != nullptr && tid == 0) p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 31] = static_cast<long long>(__builtin_readcyclecounter());
+    // stamp 31: the workgroup's last instruction (all tiles): shader cycles of the whole launch per workgroup; stamps 29 / 30: the
+    // constant 100 MHz clock (s_memrealtime) at entry / here: cycles / time = the shader clock the launch really ran at
+    if (p.timeline != nullptr && tid == 0) {
+        p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 31] = static_cast<long long>(__builtin_readcyclecounter());
+        p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 30] = static_cast<long long>(__builtin_amdgcn_s_memrealtime());
+        p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 29] = rt0;
+    }
 }
 
 template <int C, int CI, int PXT, bool NEXT>

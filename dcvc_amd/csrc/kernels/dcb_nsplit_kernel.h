@@ -186,9 +186,10 @@ dcb_nsplit_kernel(const NsParams p)
     // stamps (first tile only): 0 entry | 1 constants + first t2 in LDS | 2 dc.3 MFMAs + x | 3 dc.3 epilogue | one per
     // ffn.0 pass (MFMAs + the previous pass's epilogue) | last epilogue | ffn.2 MFMAs | epilogue | y out | dc.0 MFMAs |
     // epilogue | t1' out
+    const long long rt0 = static_cast<long long>(__builtin_amdgcn_s_memrealtime());
     int stamp_no = 0;
     auto stamp = [&]() {
-        if (p.timeline != nullptr && tid == 0 && stamp_no < 32 && tile == static_cast<int>(blockIdx.x)) {
+        if (p.timeline != nullptr && tid == 0 && stamp_no < 29 && tile == static_cast<int>(blockIdx.x)) {
             p.timeline[static_cast<size_t>(blockIdx.x) * 32 + stamp_no] = static_cast<long long>(__builtin_readcyclecounter());
         }
         ++stamp_no;
@@ -749,8 +750,13 @@ dcb_nsplit_kernel(const NsParams p)
     tile = next_tile;
     m0 = tile * PX;
     }       // tiles
-    // stamp 31: the workgroup's last instruction (all tiles): cycles of the whole launch per workgroup -> effective clock
-    if (p.timeline != nullptr && tid == 0) p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 31] = static_cast<long long>(__builtin_readcyclecounter());
+    // stamp 31: the workgroup's last instruction (all tiles): shader cycles of the whole launch per workgroup; stamps 29 / 30: the
+    // constant 100 MHz clock (s_memrealtime) at entry / here: cycles / time = the shader clock the launch really ran at
+    if (p.timeline != nullptr && tid == 0) {
+        p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 31] = static_cast<long long>(__builtin_readcyclecounter());
+        p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 30] = static_cast<long long>(__builtin_amdgcn_s_memrealtime());
+        p.timeline[static_cast<size_t>(blockIdx.x) * 32 + 29] = rt0;
+    }
 }
 template <int C, int CI, int PXT>
 constexpr int smem_bytes()

@@ -235,7 +235,7 @@ int main(int argc, char** argv)
             int nstamps = 0;
             for (size_t w = 0; w < rows && nstamps == 0; ++w) {
                 if (h[w * 32] == 0) continue;
-                for (int i = 1; i < 32 && h[w * 32 + i] != 0; ++i) nstamps = i;
+                for (int i = 1; i < 29 && h[w * 32 + i] != 0; ++i) nstamps = i;
             }
             for (int i = 0; i < nstamps; ++i) {
                 std::vector<float> d;
@@ -255,6 +255,19 @@ int main(int argc, char** argv)
             printf(" total %.0f | workgroups %zu, start of the median / last workgroup %.0f / %.0f", median(tot), tot.size(),
                    start.empty() ? 0.f : start[start.size() / 2], start.empty() ? 0.f : start.back());
             // (the counters of different XCDs are not aligned: only differences inside one workgroup mean anything)
+            // stamps 29 / 30 (round 4): the 100 MHz real-time counter at the workgroup's entry / last instruction
+            std::vector<float> ghz, span_us;
+            long long rt_first = 0, rt_last = 0;
+            for (size_t w = 0; w < rows; ++w) {
+                if (h[w * 32] == 0 || h[w * 32 + 30] == 0 || h[w * 32 + 29] == 0) continue;
+                const double us = static_cast<double>(h[w * 32 + 30] - h[w * 32 + 29]) / 100.0;
+                if (us > 0) { ghz.push_back(static_cast<float>((h[w * 32 + 31] - h[w * 32]) / us / 1e3)); span_us.push_back(static_cast<float>(us)); }
+                if (rt_first == 0 || h[w * 32 + 29] < rt_first) rt_first = h[w * 32 + 29];
+                rt_last = std::max(rt_last, h[w * 32 + 30]);
+            }
+            if (!ghz.empty()) printf(" | shader clock inside the launch %.2f GHz (cycles / 100 MHz real-time counter, median workgroup); workgroups run %.1f us (median), "
+                                     "first entry to last exit %.1f us of the launch's %.1f us",
+                                     median(ghz), median(span_us), static_cast<double>(rt_last - rt_first) / 100.0, median(l.us_ns_next));
             if (!whole.empty()) {
                 std::sort(whole.begin(), whole.end());
                 printf(" | whole launch, cycles per workgroup: min %.0f, median %.0f, p90 %.0f, max %.0f; max / wall time %.1f us = %.2f GHz",
