@@ -4,6 +4,7 @@
 #include "codec/dmc_ld.h"
 #include "codec/dmci.h"
 #include "dcvc_amd_codec.h"
+#include "kernels/arith.h"
 
 #include <cstring>
 
@@ -45,6 +46,8 @@ void check_padding16(int height, int width, int padding_b, int padding_r)
 }  // namespace
 
 extern "C" {
+
+int dcvc_arith_policy_version(void) { return dcvc::kArithPolicyVersion; }
 
 dcvc_dmci* dcvc_dmci_create(void)
 {

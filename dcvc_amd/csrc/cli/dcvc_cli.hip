@@ -469,7 +469,7 @@ int decode(const Args& a)
         FILE* jf = fopen(a.str("json").c_str(), "w");
         if (!jf) die("cannot write " + a.str("json"));
         const char* sfx[4] = {"", "_y", "_u", "_v"};
-        fprintf(jf, "{\n  \"frame_pixel_num\": %.0f,\n  \"i_frame_num\": %d,\n  \"p_frame_num\": %d,\n", px, ni, np);
+        fprintf(jf, "{\n  \"arith_policy\": %d,\n  \"frame_pixel_num\": %.0f,\n  \"i_frame_num\": %d,\n  \"p_frame_num\": %d,\n", dcvc_arith_policy_version(), px, ni, np);
         fprintf(jf, "  \"ave_i_frame_bpp\": %.9g,\n  \"ave_p_frame_bpp\": %.9g,\n", ni ? ib / ni / px : 0.0, np ? pb / np / px : 0.0);
         for (int k = 0; k < 4; ++k) {
             fprintf(jf, "  \"ave_i_frame_psnr%s\": %.9g,\n  \"ave_p_frame_psnr%s\": %.9g,\n  \"ave_all_frame_psnr%s\": %.9g,\n", sfx[k],

@@ -40,6 +40,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 // tab[e * R]: R = 1 is the plain 4 KiB table; the contraction kernels' epilogues use R interleaved copies
 // with every lane reading "its own" copy (tab already offset by lane & (R - 1)), which spreads the 16
 // lanes of a ds_read_b128 group over 16-byte bank slots whatever entries they ask for.
+constexpr int kArithPolicyVersion = 3;       // dcvc_arith_policy_version(): bump with ANY change that moves a stored fp16 / symbol
 constexpr float kWsiluLo = -4.0f;
 constexpr float kWsiluHi = 3.998046875f;     // 4 - 2^-9
 constexpr float kWsiluMagic = 4100.0f;       // 2^12 + 4

@@ -45,6 +45,7 @@ class TargetBpp:
         self.horizon, self.intra_bonus = max(1, int(horizon)), int(intra_bonus)
         self.qp_min, self.qp_max = int(qp_min), int(qp_max)
         self.slope = float(slope)
+        self.max_step = 4.0                                                # q_index steps per update
         self.spent, self.pictures = 0.0, 0
         self._last = None                                                  # (qp, log2 bits per picture) of the last P unit
 
@@ -68,7 +69,16 @@ class TargetBpp:
         # bits the next `horizon` pictures may take so that the running average lands on the target
         budget = self.target_bits * (self.pictures + self.horizon) - self.spent
         want = max(budget / self.horizon, self.target_bits / 64.0)
-        self.qp += (math.log2(want) - math.log2(per_picture)) / self.slope * (0.5 if is_intra else 1.0)
+        if is_intra:
+            # An I picture costs several times the per-picture target by design: its bits count in `spent` (the budget above
+            # already pays them back over the horizon), but its SIZE says nothing about what the P units cost at this qp, so it
+            # does not enter the proportional term (advisor, round 3: it used to drop qp by ~34 steps behind every I picture).
+            # Only the budget it leaves moves qp, measured against the last P unit if there is one.
+            if self._last is None:
+                return
+            per_picture = 2.0 ** self._last[1]
+        step = (math.log2(want) - math.log2(per_picture)) / self.slope
+        self.qp += min(self.max_step, max(-self.max_step, step))           # bounded step: no oscillation with the intra period
         self.qp = min(float(self.qp_max), max(float(self.qp_min), self.qp))
 
     @property

@@ -25,6 +25,13 @@ extern "C" {
 const char* dcvc_last_error(void);
 #endif
 
+/* Version of the arithmetic policy this build computes with (contraction order and rounding points, the WSiLU
+ * evaluation, the symbol kernels' fp16 steps). Streams decode bit-exactly only between builds of the SAME version: the
+ * container (the reference's own, stream_helper.py:130-154) has no field for it, so callers that keep streams around record
+ * it beside them - the native tool writes it into its JSON logs. Round 2: 2, rounds 3 and 4: 3. No reference counterpart (the
+ * reference makes no cross-build guarantee). */
+int dcvc_arith_policy_version(void);
+
 typedef struct dcvc_dmci dcvc_dmci;
 
 /* tensor element types of dcvc_*_set_param */

@@ -87,3 +87,23 @@ def test_units_carry_what_the_container_stores():
         assert (h["nal_type"] == sh.NalType.NAL_I) == intra
         got_qp, ec, got_reset, got = sh.read_ip_remaining(f)
         assert (got_qp, bool(got_reset), bytes(got)) == (qp, bool(reset), payload)
+
+
+def test_an_intra_picture_does_not_kick_the_controller():
+    """advisor, round 3: an I picture costs ~ 20x a P picture here; its bits enter the budget, not the proportional term - the
+    q_index of the P units behind every I picture stays within the bounded step of the one in front of it, and the sequence
+    still lands near the budget."""
+    pixels = 1920 * 1080
+    bits = _fake_codec(pixels, seed=3)
+    target = 0.06
+    c = rc.TargetBpp(target, pixels, qp0=30)
+    units = rc.code_sequence(161, 1, lambda i, q: b"\0" * (bits(q, 1, True) // 8), lambda i, n, q, r: b"\0" * (bits(q, n, False) // 8), c,
+                             intra_period=32)
+    qps = [u[1] for u in units]
+    kinds = [u[0] for u in units]
+    for k in range(2, len(units) - 1):
+        if kinds[k]:                                           # P in front of the I picture, P behind it
+            assert abs(qps[k + 1] - qps[k - 1]) <= 2 * c.max_step + 1, (k, qps[k - 1:k + 2])
+    steps = [abs(qps[k + 1] - qps[k]) for k in range(len(units) - 1) if not kinds[k] and not kinds[k + 1]]
+    assert max(steps) <= c.max_step + 1
+    assert abs(c.spent_bits_per_picture / pixels - target) / target < 0.2
