@@ -71,8 +71,10 @@ def parse_args():
     p.add_argument("--fanout", action="store_true",
                    help="hts / htl with --gpus N > 1: ONE stream, the 8 reconstruction heads of a chunk spread over the ranks "
                         "(feature_p broadcast over RCCL; strong scaling) instead of N independent streams")
-    p.add_argument("--two-codecs", action="store_true",
-                   help="intra: separate encoder / decoder codec objects (default: one object, as the reference harness)")
+    p.add_argument("--one-codec", action="store_true",
+                   help="intra: ONE codec object codes and decodes, one call after the other (as the reference harness uses its "
+                        "i_frame_net). Default since round 4: separate encoder / decoder objects run as a two-stage pipeline")
+    p.add_argument("--two-codecs", action="store_true", help="(the default; kept for old command lines)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the short runs of the other three workloads")
@@ -135,10 +137,12 @@ def make_pictures(n, rank, device, height=HEIGHT, width=WIDTH):
 
 
 class IntraWorkload:
-    """configs[1]: every picture is an I picture. One codec object codes and decodes (`dec_net=None`), as the
-    reference harness uses its i_frame_net; `--two-codecs` gives the decoder its own object (own stream: its
-    prior stages then overlap the encoder's reconstruction tail - measured SLOWER, 105.8 vs 119.6 pictures/s:
-    the two streams' full-chip kernels get in each other's way)."""
+    """configs[1]: every picture is an I picture. Default (round 4): a decoder object of its own (`dec_net`), driven as the
+    second stage of run_steps_overlapped() with its compute stream at high priority: the decoder's four host round trips per
+    picture (0.6 ms of idle GPU) are filled with the next picture's encoder kernels - 143.6 -> 148.1 pictures/s (sustained
+    150.0) on one box. The same two objects called one after the other from one thread are SLOWER than one object (125;
+    round 1 measured the same: 105.8 vs 119.6) - the decoder's short kernels queue behind the encoder's reconstruction tail at
+    equal priority. `--one-codec` (`dec_net=None`): one object codes and decodes, as the reference harness uses its i_frame_net."""
     frames, kind = 1, "intra"
 
     def __init__(self, gpu_net, pics, pad_b, pad_r, dec_net=None):
@@ -146,9 +150,17 @@ class IntraWorkload:
         self.dec = dec_net if dec_net is not None else gpu_net
         self.height, self.width = int(pics[0].shape[2]), int(pics[0].shape[3])
         self.sps = {"height": self.height, "width": self.width}
+        # --two-codecs: a decoder object of its own can run as the second stage of run_steps_overlapped()
+        self.overlapped = dec_net is not None
+        if self.overlapped and not os.environ.get("DCVC_BENCH_SEQUENTIAL") and os.environ.get("DCVC_BENCH_PRIORITIES", "1") != "0":
+            os.environ["DCVC_COMPUTE_PRIORITY"] = "high"
+            self.dec._ensure_proxy()
+            del os.environ["DCVC_COMPUTE_PRIORITY"]
 
     def prepare(self, i):
         pass
+
+    prepare_enc = prepare_dec = prepare
 
     def compress(self, i, qp):
         return self.net.compress(self.pics[i % len(self.pics)], qp, self.pad_b, self.pad_r)
@@ -194,6 +206,13 @@ class InterWorkload:
             self.frames, self.gop = 8, 12
         net.update(SKIP_THRES)
         self.enc, self.dec = _to_gpu(net, device), _to_gpu(net, device)
+        if self.overlapped and not os.environ.get("DCVC_BENCH_SEQUENTIAL") and os.environ.get("DCVC_BENCH_PRIORITIES", "1") != "0":
+            # the decoder's chain of short kernels and host round trips goes first, the encoder fills the gaps (the
+            # priority of a codec's compute stream is read when the native object is created)
+            for obj, prio in ((self.enc, "low"), (self.dec, "high")):
+                os.environ["DCVC_COMPUTE_PRIORITY"] = prio
+                obj._ensure_proxy()
+            del os.environ["DCVC_COMPUTE_PRIORITY"]
         self.ref = gpu_intra.compress(pics[0], 32, pad_b, pad_r)["x_hat"].clone()
         if self.frames == 1:
             self.inputs = pics
@@ -208,10 +227,21 @@ class InterWorkload:
         frame_idx = 1 + self.frames * (i % self.gop)
         return 1 if (frame_idx + self.frames) % self.RESET_INTERVAL == 1 else 0
 
-    def prepare(self, i):
+    # encoder and decoder are separate objects that share nothing but the bytes: run_steps_overlapped() drives them as a
+    # two-stage pipeline from two host threads (a real deployment runs them on different machines)
+    overlapped = True
+
+    def prepare_enc(self, i):
         if i % self.gop == 0:
             self.enc.add_ref_feature_from_frame(self.ref)
+
+    def prepare_dec(self, i):
+        if i % self.gop == 0:
             self.dec.add_ref_feature_from_frame(self.ref, apply_feature_adaptor=False)
+
+    def prepare(self, i):
+        self.prepare_enc(i)
+        self.prepare_dec(i)
 
     def compress(self, i, qp):
         return self.enc.compress(self.inputs[i % len(self.inputs)], qp, self._reset(i), self.pad_b, self.pad_r)
@@ -242,6 +272,7 @@ class FanoutWorkload(InterWorkload):
     decoder's entropy / prior / decoder stages, temporal state); it broadcasts feature_p over RCCL while its own
     reconstruction heads run, and every rank reconstructs its share of the 8 pictures
     (dcvc_amd/sharding.py decompress_fanout). Strong scaling: the work of a step does not grow with the number of GPUs."""
+    overlapped = False          # every rank takes part in every decompress call: one thread
 
     def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r, dist):
         super().__init__(kind, device, pics, gpu_intra, pad_b, pad_r)
@@ -281,6 +312,67 @@ def run_steps(work, first, n):
     return nbytes
 
 
+def run_steps_overlapped(work, first, n, depth=int(os.environ.get("DCVC_BENCH_DEPTH", "2"))):
+    """The same n steps as a two-stage pipeline: an encoder thread codes step i + 1 (its own stream) while this thread
+    decodes step i. What it buys: the decoder's host round trips - entropy decoding of a whole P picture is 0.7 ms with
+    the GPU idle (profiles/r04_ld_timeline.txt) - are filled with the encoder's kernels of the next picture, and the
+    encoder's host entropy coding with the decoder's kernels. Encoder and decoder objects share nothing but the bytes (a
+    fresh numpy copy per call); both see the steps in order, so GOP re-seeding and memory resets stay in lock-step. The
+    codec calls are ctypes calls: the GIL is released inside them."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    device = torch.cuda.current_device()
+    stream = getattr(work, "_enc_stream", None)
+    if stream is None:
+        stream = work._enc_stream = torch.cuda.Stream(device)
+    failed = []
+
+    def encoder():
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(stream):
+                for i in range(first, first + n):
+                    qp = QPS[i % len(QPS)]
+                    work.prepare_enc(i)
+                    q.put((i, qp, work.compress(i, qp)))
+        except BaseException as e:           # noqa: BLE001 - handed to the caller's thread
+            failed.append(e)
+        finally:
+            q.put(None)
+
+    t = threading.Thread(target=encoder, name="bench-encoder")
+    t.start()
+    nbytes = 0
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            i, qp, enc = item
+            work.prepare_dec(i)
+            work.decompress(i, qp, enc)
+            nbytes += len(enc["bit_stream"])
+    finally:
+        while t.is_alive():                  # a decoder failure must not leave the encoder blocked on a full queue
+            try:
+                q.get(timeout=0.1)
+            except queue.Empty:
+                pass
+        t.join()
+    if failed:
+        raise failed[0]
+    return nbytes
+
+
+def step_loop(work):
+    """run_steps for one codec object / the fan-out, the two-stage pipeline for separate encoder / decoder objects
+    (DCVC_BENCH_SEQUENTIAL=1: always the plain loop - the A/B partner)"""
+    if getattr(work, "overlapped", False) and not os.environ.get("DCVC_BENCH_SEQUENTIAL"):
+        return run_steps_overlapped
+    return run_steps
+
+
 def call_times(work, first, n):
     """The reference's timing loop (test_video.py:224-265, 300-325): synchronise, event, call, event,
     synchronise - per call. Returns mean seconds per compress / per decompress call, first 4 dropped."""
@@ -312,18 +404,29 @@ def closure_ok(work, first):
 
 def fps_block(work, first, steps, warmup, with_roofline=False):
     """throughput (pipelined loop) + the reference-style encode / decode rates of one workload"""
-    run_steps(work, first, warmup)
+    run_steps(work, first, warmup)           # (plain loop: graph capture of both objects from one thread)
     torch.cuda.synchronize()
+    loop = step_loop(work)
     t0 = time.perf_counter()
-    nbytes = run_steps(work, first + warmup, steps)
+    nbytes = loop(work, first + warmup, steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    first += steps
+    seq = None
+    if loop is not run_steps:                # the plain loop beside it (one call after the other, as round 3 measured)
+        t0 = time.perf_counter()
+        run_steps(work, first + warmup, steps)
+        torch.cuda.synchronize()
+        seq = steps * work.frames / (time.perf_counter() - t0)
+        first += steps
     ncalls = min(steps, 24) + DROP_CALLS
-    te, td = call_times(work, first + warmup + steps, ncalls)
+    te, td = call_times(work, first + warmup, ncalls)
     out = {"value": steps * work.frames / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "loop": "two-stage pipeline (encoder thread | decoder thread)" if seq is not None else "one call after the other",
+           "value_sequential": seq,
            "encode_fps": work.frames / te, "decode_fps": work.frames / td,
            "bpp": 8.0 * nbytes / steps / work.frames / (work.height * work.width),
-           "closure_ok": closure_ok(work, first + warmup + steps + ncalls)}
+           "closure_ok": closure_ok(work, first + warmup + ncalls)}
     if with_roofline:
         r = roofline(work, n=2)
         out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "all_contractions")}
@@ -528,7 +631,7 @@ def main():
         pics = make_pictures(frames, rank, device, h, w)
         pad_r, pad_b = gpu_net.get_padding_size(h, w, 16)
         if kind == "intra":
-            return IntraWorkload(gpu_net, pics, pad_b, pad_r, _to_gpu(cpu_net, device) if args.two_codecs else None)
+            return IntraWorkload(gpu_net, pics, pad_b, pad_r, None if args.one_codec else _to_gpu(cpu_net, device))
         return InterWorkload(kind, device, pics, gpu_net, pad_b, pad_r)
 
     fanout = args.fanout and world > 1
@@ -561,10 +664,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    run_steps(work, 0, args.warmup)
+    run_steps(work, 0, args.warmup)          # (plain loop: the codecs capture their graphs from one thread)
+    loop = step_loop(work)
     sync()
     t0 = time.perf_counter()
-    nbytes = run_steps(work, args.warmup + mine.start, args.steps)
+    nbytes = loop(work, args.warmup + mine.start, args.steps)
     sync()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
@@ -575,17 +679,38 @@ def main():
         more = min(more, 100 * args.steps)
         sync()
         t0 = time.perf_counter()
-        run_steps(work, args.warmup + mine.start + args.steps, more)
+        loop(work, args.warmup + mine.start + args.steps, more)
         sync()
         t_more = max_over_ranks(time.perf_counter() - t0)
         sustained = {"steps": more, "seconds": t_more, "value": (1 if fanout else world) * more * work.frames / t_more,
                      "unit": "frames/s"}
 
+    # the plain loop beside the two-stage pipeline (rank 0, short): one call after the other on the same objects for the inter
+    # models; for the intra model ONE codec object coding and decoding, as the reference harness does
+    plain = None
+    if rank == 0 and loop is not run_steps:
+        n_plain = min(args.steps, 30)
+        first_plain = args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0)
+        w_plain = IntraWorkload(work.net, work.pics, work.pad_b, work.pad_r, None) if args.workload == "intra" else work
+        run_steps(w_plain, first_plain, 4 if w_plain is not work else 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(w_plain, first_plain + 4, n_plain)
+        torch.cuda.synchronize()
+        plain = {"value": n_plain * work.frames / (time.perf_counter() - t0), "unit": "frames/s (this rank)", "steps": n_plain,
+                 "loop": "one codec object, compress then decompress (the reference harness's way)" if w_plain is not work
+                         else "the same encoder / decoder objects, one call after the other"}
+        if w_plain is work:
+            sustained_steps_done = n_plain + 4
+        else:
+            sustained_steps_done = 0
+    else:
+        sustained_steps_done = 0
     ncalls = min(args.steps, 32) + DROP_CALLS
     if fanout:       # every rank takes part in the per-call timing loop (the broadcast is a collective)
         te, td = call_times(work, args.warmup + args.steps, ncalls)
     # every rank checks ITS codec objects after the timed regions (fan-out: the shared stream is checked by the tests)
-    closure = None if fanout else closure_ok(work, args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0))
+    closure = None if fanout else closure_ok(work, args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0) + sustained_steps_done)
     if dist is not None and closure is not None:
         flag = torch.tensor([1.0 if closure else 0.0], dtype=torch.float64, device=comm_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -608,18 +733,23 @@ def main():
                                    + "q_index cycling {0,16,32,48,63}, skip_thres 0.15, one step = compress + decompress of %d "
                                      "picture(s)" % work.frames,
                        "sharding": "recon-head fan-out" if fanout else "independent streams (sharding.shard_range)",
-                       "codec_objects": "one" if (args.workload == "intra" and not args.two_codecs) else "separate encoder / decoder",
+                       "codec_objects": "one" if (args.workload == "intra" and args.one_codec) else "separate encoder / decoder",
                        "pictures_per_step": work.frames, "resolution": res},
             "encode_fps": work.frames / te, "decode_fps": work.frames / td,
             "avg_frame_encoding_time_ms": 1e3 * te / work.frames, "avg_frame_decoding_time_ms": 1e3 * td / work.frames,
             "fps_method": "value: K pipelined steps between device synchronisations; encode_fps / decode_fps: the reference's loop "
                           "(events around each call on a synchronised device, first %d calls dropped, rank 0)" % DROP_CALLS,
+            "loop": "two-stage pipeline: an encoder thread codes step i + 1 while the decoder thread decodes step i (separate "
+                    "encoder / decoder objects; DCVC_BENCH_SEQUENTIAL=1 = one call after the other)" if loop is not run_steps
+                    else "one call after the other (one codec object codes and decodes)",
             "bytes_per_picture": nbytes / args.steps / work.frames,
             "bpp": 8.0 * nbytes / args.steps / work.frames / (height * width),
             "closure_ok": closure,
         }
         if sustained is not None:
             out["sustained"] = sustained
+        if plain is not None:
+            out["plain_loop"] = plain
         if not args.no_roofline and not fanout:
             out["roofline"] = roofline(work)
         if world == 1 and not args.no_extras:
@@ -630,7 +760,7 @@ def main():
                 if kind == args.workload:
                     continue
                 w = make_work(kind, height, width)
-                others[kind] = fps_block(w, 0, 24 if kind in ("hts", "htl") else 48, 6, with_roofline=not args.no_roofline)
+                others[kind] = fps_block(w, 0, 36 if kind in ("hts", "htl") else 96, 12, with_roofline=not args.no_roofline)
                 del w
                 torch.cuda.empty_cache()
             out["other_workloads"] = others

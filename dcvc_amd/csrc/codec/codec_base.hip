@@ -13,7 +13,15 @@ CodecBase::CodecBase()
     int lo = 0, hi = 0;
     hip_check(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
     hip_check(hipStreamCreateWithPriority(&m_io_stream, hipStreamNonBlocking, hi), "hipStreamCreate(io)");
-    hip_check(hipStreamCreateWithFlags(&m_cs, hipStreamNonBlocking), "hipStreamCreate(compute)");
+    // DCVC_COMPUTE_PRIORITY = high | low, read when a codec object is created: the priority of its compute stream. A
+    // decoder that shares a GPU with an encoder (bench.py's two-stage loop) is a chain of short kernels and host round
+    // trips - at equal priority every one of them queues behind a kernel of the encoder's burst
+    int prio = 0;
+    if (const char* e = getenv("DCVC_COMPUTE_PRIORITY")) {
+        const std::string v(e);
+        prio = v == "high" ? hi : v == "low" ? lo : 0;
+    }
+    hip_check(hipStreamCreateWithPriority(&m_cs, hipStreamNonBlocking, prio), "hipStreamCreate(compute)");
     hip_check(hipEventCreateWithFlags(&m_ev_job, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&m_ev_in, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&m_ev_out, hipEventDisableTiming), "hipEventCreate");

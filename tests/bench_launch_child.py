@@ -23,6 +23,8 @@ def install():
     torch.cuda.Stream = fakes._FakeStream
     torch.cuda.Event = fakes._FakeEvent
     torch.cuda.set_stream = lambda s: None
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.stream = lambda s: __import__("contextlib").nullcontext()
     torch.cuda.synchronize = lambda d=None: None
     torch.cuda.empty_cache = lambda: None
     __graft_entry__.build = lambda: None

@@ -82,10 +82,19 @@ class _FakeWork:
 
 
 class _FakeInter(_FakeWork):
+    overlapped = True
+
     def __init__(self, kind, *a, **k):
         super().__init__(*a, **k)
         self.kind = kind
         self.frames = 1 if kind == "ld" else 8
+        self.enc_prepared, self.dec_prepared = [], []
+
+    def prepare_enc(self, i):
+        self.enc_prepared.append(i)
+
+    def prepare_dec(self, i):
+        self.dec_prepared.append(i)
 
 
 @pytest.fixture
@@ -96,6 +105,8 @@ def fake_gpu(monkeypatch):
     monkeypatch.setattr(torch.cuda, "Stream", _FakeStream)
     monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
     monkeypatch.setattr(torch.cuda, "set_stream", lambda s: None)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: __import__("contextlib").nullcontext())
     monkeypatch.setattr(torch.cuda, "synchronize", lambda d=None: None)
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
     monkeypatch.setattr(__graft_entry__, "build", lambda: None)
@@ -184,10 +195,38 @@ def test_reset_cadence_of_the_inter_workloads():
 
 
 def test_inter_workload_line(fake_gpu, monkeypatch, capsys):
-    d = _run(monkeypatch, capsys, ["--steps", "4", "--warmup", "1", "--workload", "hts", "--no-extras", "--min-seconds", "0.1"])
+    d = _run(monkeypatch, capsys, ["--steps", "6", "--warmup", "1", "--workload", "hts", "--no-extras", "--min-seconds", "0"])
     assert d["config"]["pictures_per_step"] == 8 and "HT-S" in d["metric"]
-    assert d["value"] == pytest.approx(8 * 4 / (d["ms_per_step"] * 4 / 1e3), rel=1e-6)
+    assert d["value"] == pytest.approx(8 * 6 / (d["ms_per_step"] * 6 / 1e3), rel=1e-6)
     assert "cpu_baseline" not in d                        # the CPU baseline belongs to the headline workload
+    # separate encoder / decoder objects: the timed steps run as a two-stage pipeline (compress 4 ms | decompress 8 ms in the
+    # stand-in: a step costs ~ 8 ms instead of 12), every step coded and decoded exactly once, in order, on both sides
+    assert "two-stage pipeline" in d["loop"]
+    w = _FakeWork.made[0]
+    assert w.enc_prepared == w.dec_prepared == list(range(1, 7))
+    timed = [c for c in w.calls if 1 <= c[1] <= 6]
+    assert sorted(timed) == sorted([("c", i) for i in range(1, 7)] + [("d", i) for i in range(1, 7)])
+    assert [i for k, i in timed if k == "d"] == list(range(1, 7))
+    assert d["ms_per_step"] < 11.0
+
+
+def test_sequential_switch(fake_gpu, monkeypatch, capsys):
+    monkeypatch.setenv("DCVC_BENCH_SEQUENTIAL", "1")
+    d = _run(monkeypatch, capsys, ["--steps", "3", "--warmup", "1", "--workload", "ld", "--no-extras", "--min-seconds", "0"])
+    assert "one call after the other" in d["loop"] and d["ms_per_step"] > 11.0
+
+
+def test_a_failing_encoder_thread_surfaces(fake_gpu, monkeypatch):
+    w = _FakeInter("ld")
+
+    def boom(i, qp):
+        if i == 2:
+            raise RuntimeError("encoder failed")
+        return {"bit_stream": b"x", "ec_parallel": 1}
+
+    w.compress = boom
+    with pytest.raises(RuntimeError, match="encoder failed"):
+        bench.run_steps_overlapped(w, 0, 5)
 
 
 class _FakeDist:
