@@ -584,6 +584,14 @@ def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inpla
     (512, 512, 12700, False, False, False, True, True),
     (256, 256, 12288, False, True, False, True, False),
     (256, 128, 12001, True, False, False, True, False),
+    # round 4: the 256-wide blocks on large ragged grids and on the 3840x2160 grid (129 600 pixels: 8 tiles per persistent
+    # workgroup). (Written for a 128-pixel-per-workgroup form of the 8-wave kernel that was bit-identical and no faster -
+    # 27.8 vs 27.6 us at (256, 128), 44.8 vs 44.1 at (256, 256) - and was dropped: DESIGN.md 5, round 4.)
+    (256, 128, 30001, True, False, True, True, False),
+    (256, 128, 129600, False, True, False, True, True),
+    (256, 256, 30001, False, True, False, True, False),
+    (256, 256, 27000, True, False, True, False, False),
+    (256, 256, 129600, False, False, False, True, True),
 ])
 def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, nxt, inplace):
     """The same block through kernels/dcb_nsplit.hip (round 3: activations in LDS, every wave streams its quarter of
