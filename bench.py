@@ -396,6 +396,32 @@ def call_times(work, first, n):
     return float(np.mean(enc_t[keep])), float(np.mean(dec_t[keep]))
 
 
+def box_identity(device):
+    """which machine produced the line (boxes of one pool differ by +- 8 % on this workload: power / clock policy)"""
+    out = {}
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        out["gpu"] = getattr(pr, "name", None)
+        uuid = getattr(pr, "uuid", None)
+        out["gpu_uuid"] = str(uuid) if uuid is not None else None
+        out["gcn_arch"] = getattr(pr, "gcnArchName", None)
+    except Exception as e:          # noqa: BLE001 - identification only
+        out["gpu"] = "unknown (%s)" % type(e).__name__
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+        out["host_cpu"] = names[0] if names else None
+        out["host_threads"] = len(names)
+    except OSError:
+        pass
+    try:
+        with open(os.path.join(ROOT, ".git_head")) as f:
+            out["commit"] = f.read().strip()
+    except OSError:
+        pass
+    return out
+
+
 def closure_ok(work, first):
     """After a timed region: one compress / decompress per rate point of QPS, checked (a throughput number from
     a desynchronised codec would otherwise look like any other). Continues the workload's stream at step `first`."""
@@ -740,6 +766,7 @@ def main():
             "bytes_per_picture": nbytes / args.steps / work.frames,
             "bpp": 8.0 * nbytes / args.steps / work.frames / (height * width),
             "closure_ok": closure,
+            "box": box_identity(device),
         }
         if sustained is not None:
             out["sustained"] = sustained
