@@ -431,8 +431,11 @@ def closure_ok(work, first):
 def fps_block(work, first, steps, warmup, with_roofline=False):
     """throughput (pipelined loop) + the reference-style encode / decode rates of one workload"""
     run_steps(work, first, warmup)           # (plain loop: graph capture of both objects from one thread)
-    torch.cuda.synchronize()
     loop = step_loop(work)
+    if loop is not run_steps:
+        loop(work, first + warmup, 2)        # the pipeline's own set-up outside the timed region
+        first += 2
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     nbytes = loop(work, first + warmup, steps)
     torch.cuda.synchronize()
@@ -686,6 +689,11 @@ def main():
 
     run_steps(work, 0, args.warmup)          # (plain loop: the codecs capture their graphs from one thread)
     loop = step_loop(work)
+    if loop is not run_steps:
+        # two more untimed steps through the pipeline itself: the encoder thread's stream and the first hand-overs between
+        # the two threads are set up outside the timed region (they cost ~ 7 ms of a 20-step region otherwise)
+        loop(work, args.warmup, 2)
+        mine = range(mine.start + 2, mine.stop + 2)
     sync()
     t0 = time.perf_counter()
     nbytes = loop(work, args.warmup + mine.start, args.steps)
@@ -705,40 +713,34 @@ def main():
         sustained = {"steps": more, "seconds": t_more, "value": (1 if fanout else world) * more * work.frames / t_more,
                      "unit": "frames/s"}
 
+    # step index behind everything this rank has coded so far (the inter workloads' GOP / reset cadence follows the index)
+    cursor = args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0)
     # beside the two-stage pipeline (rank 0, short, intra): ONE codec object coding and decoding, as the reference harness does.
     # (Inter models: DCVC_BENCH_SEQUENTIAL=1 is the A/B partner - on objects whose streams carry priorities the plain loop
     # runs slower than it does without them.)
     plain = None
     if rank == 0 and loop is not run_steps and args.workload == "intra":
         n_plain = min(args.steps, 30)
-        first_plain = args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0)
-        w_plain = IntraWorkload(work.net, work.pics, work.pad_b, work.pad_r, None) if args.workload == "intra" else work
-        run_steps(w_plain, first_plain, 4 if w_plain is not work else 0)
+        w_plain = IntraWorkload(work.net, work.pics, work.pad_b, work.pad_r, None)
+        run_steps(w_plain, cursor, 4)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(w_plain, first_plain + 4, n_plain)
+        run_steps(w_plain, cursor + 4, n_plain)
         torch.cuda.synchronize()
         plain = {"value": n_plain * work.frames / (time.perf_counter() - t0), "unit": "frames/s (this rank)", "steps": n_plain,
-                 "loop": "one codec object, compress then decompress (the reference harness's way)" if w_plain is not work
-                         else "the same encoder / decoder objects, one call after the other"}
-        if w_plain is work:
-            sustained_steps_done = n_plain + 4
-        else:
-            sustained_steps_done = 0
-    else:
-        sustained_steps_done = 0
+                 "loop": "one codec object, compress then decompress (the reference harness's way)"}
     ncalls = min(args.steps, 32) + DROP_CALLS
     if fanout:       # every rank takes part in the per-call timing loop (the broadcast is a collective)
-        te, td = call_times(work, args.warmup + args.steps, ncalls)
+        te, td = call_times(work, cursor, ncalls)
     # every rank checks ITS codec objects after the timed regions (fan-out: the shared stream is checked by the tests)
-    closure = None if fanout else closure_ok(work, args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0) + sustained_steps_done)
+    closure = None if fanout else closure_ok(work, cursor + ncalls)
     if dist is not None and closure is not None:
         flag = torch.tensor([1.0 if closure else 0.0], dtype=torch.float64, device=comm_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         closure = bool(flag.item() > 0.5)
     if rank == 0:
         if not fanout:
-            te, td = call_times(work, args.warmup + args.steps, ncalls)
+            te, td = call_times(work, cursor, ncalls)
         fps = (1 if fanout else world) * args.steps * work.frames / elapsed
         res = "%dx%d" % (width, height)
         out = {

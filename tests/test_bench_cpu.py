@@ -203,10 +203,11 @@ def test_inter_workload_line(fake_gpu, monkeypatch, capsys):
     # stand-in: a step costs ~ 8 ms instead of 12), every step coded and decoded exactly once, in order, on both sides
     assert "two-stage pipeline" in d["loop"]
     w = _FakeWork.made[0]
-    assert w.enc_prepared == w.dec_prepared == list(range(1, 7))
-    timed = [c for c in w.calls if 1 <= c[1] <= 6]
-    assert sorted(timed) == sorted([("c", i) for i in range(1, 7)] + [("d", i) for i in range(1, 7)])
-    assert [i for k, i in timed if k == "d"] == list(range(1, 7))
+    # step 0 = the plain warm-up, steps 1 - 2 = the pipeline's own untimed warm-up, steps 3 - 8 = the six timed steps
+    assert w.enc_prepared == w.dec_prepared == list(range(1, 9))
+    timed = [c for c in w.calls if 3 <= c[1] <= 8]
+    assert sorted(timed) == sorted([("c", i) for i in range(3, 9)] + [("d", i) for i in range(3, 9)])
+    assert [i for k, i in timed if k == "d"] == list(range(3, 9))
     assert d["ms_per_step"] < 11.0
 
 
