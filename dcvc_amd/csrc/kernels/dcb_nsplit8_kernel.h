@@ -50,6 +50,30 @@ constexpr int RING = NS8_RING;           // weight fragments in flight per wave 
 #endif
 constexpr int GB = NS8_GATHERS;          // table gathers in flight in the WSiLU epilogues (4 registers each)
 
+// LDS layout. TRIPLE (NS8_TRIPLE, where it fits): a SECOND t2 buffer A' behind B, so that the next tile's t2 can land while the
+// current tile still works in A - its transfer goes out in front of the last ffn.0 pass's epilogue (no weights are requested
+// behind it for a while) instead of behind a barrier of its own after ffn.2's MFMAs. A and A' swap roles every tile. The 384-wide
+// blocks have room for it only with ONE copy of the WSiLU table (3 x 48 KB + 4 KB + constants = exactly 160 KB).
+#ifndef NS8_TRIPLE
+#define NS8_TRIPLE 1
+#endif
+template <int C, int CI, int PXT>
+struct Lay {
+    static constexpr int BUF_A = 32 * PXT * CI * 2, BUF_B = 32 * PXT * C * 2;
+    static constexpr int CONSTS = (2 * C + 5 * CI) * 4 + 2 * C * 2;
+    static constexpr bool FIT4 = 2 * BUF_A + BUF_B + 4 * TABLE_BYTES + CONSTS <= 160 * 1024 && (2 * BUF_A + BUF_B) % 16384 == 0;
+    static constexpr bool FIT1 = 2 * BUF_A + BUF_B + 1 * TABLE_BYTES + CONSTS <= 160 * 1024 && (2 * BUF_A + BUF_B) % 4096 == 0;
+    static constexpr bool TRIPLE = NS8_TRIPLE != 0 && (FIT4 || FIT1);
+    static constexpr int RT = TRIPLE ? (FIT4 ? 4 : 1) : R;           // interleaved copies of the WSiLU table
+    static constexpr int OFF_B = BUF_A;
+    static constexpr int OFF_A2 = BUF_A + BUF_B;
+    static constexpr int OFF_TABLE = TRIPLE ? 2 * BUF_A + BUF_B : align16k(BUF_A + BUF_B);
+    static constexpr int OFF_BIAS = OFF_TABLE + RT * TABLE_BYTES;
+    static constexpr int OFF_Q = OFF_BIAS + (2 * C + 5 * CI) * 4;
+    static constexpr int BYTES = OFF_Q + 2 * C * 2;
+    static_assert(BYTES <= 160 * 1024, "LDS budget");
+};
+
 // Per-wave tile / fragment counts. A "tile" = 32 output channels; a fragment = one MFMA "A" operand (32 channels x 16 k).
 template <int C, int CI>
 struct Geo {
@@ -79,12 +103,14 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     constexpr int F_DC3 = G::f_dc3(HIW), F_FFN0 = G::F_FFN0, F_MAIN = G::f_main(HIW), F_DC0 = G::f_dc0(HIW);
     constexpr int CH_C = C / 8, CH_I = CI / 8;                  // 16-byte chunks per row
     constexpr int PITCH_C = C * 2, PITCH_I = CI * 2;
-    constexpr int BUF_A = PX * PITCH_I, BUF_B = PX * PITCH_C;
-    constexpr int OFF_B = BUF_A;
-    constexpr int OFF_TABLE = align16k(BUF_A + BUF_B);
-    constexpr int OFF_BIAS = OFF_TABLE + R * TABLE_BYTES;           // fp32: b3 (C) | b0 (4 CI) | b2 (C) | b1n (CI)
+    using L = Lay<C, CI, PXT>;
+    constexpr bool TRIPLE = L::TRIPLE;
+    constexpr int RT = L::RT;
+    constexpr int OFF_B = L::OFF_B, OFF_A2 = L::OFF_A2;
+    constexpr int OFF_TABLE = L::OFF_TABLE;
+    constexpr int OFF_BIAS = L::OFF_BIAS;                           // fp32: b3 (C) | b0 (4 CI) | b2 (C) | b1n (CI)
     constexpr int BIAS_FLOATS = 2 * C + 5 * CI;
-    constexpr int OFF_Q = OFF_BIAS + BIAS_FLOATS * 4;               // fp16: q | q2
+    constexpr int OFF_Q = L::OFF_Q;                                 // fp16: q | q2
     constexpr int TOTAL = F_MAIN + (NEXT ? F_DC0 : 0);
     static_assert((PX * CH_C) % NTHREADS == 0 && (PX * CH_I) % NTHREADS == 0, "tile rows must split evenly over the threads");
 
@@ -118,9 +144,9 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     stamp();
 
     // ---- constants into registers first (all loads independent), written to LDS behind the first tile's transfers
-    constexpr int TAB_PER_THREAD = R * WSILU_SEGMENTS / NTHREADS;
-    static_assert(TAB_PER_THREAD == 2, "two table rows per thread, spelled out");
-    const float4 tab0 = p.wsilu[tid / R], tab1 = p.wsilu[(tid + NTHREADS) / R];
+    // RT copies of the 256 table rows, interleaved: slot s = row s / RT (RT = 4: two slots per thread; RT = 1: the first 256 threads)
+    static_assert(RT == 4 || RT == 1, "table slots per thread, spelled out");
+    const float4 tab0 = p.wsilu[min(tid / RT, WSILU_SEGMENTS - 1)], tab1 = p.wsilu[min((tid + NTHREADS) / RT, WSILU_SEGMENTS - 1)];
     constexpr int CONST_UNITS = (BIAS_FLOATS + 2 * C) / 8;      // b3 | b0 | b2 | b1n | q | q2 in 8-channel units
     constexpr int CONST_PER_THREAD = (CONST_UNITS + NTHREADS - 1) / NTHREADS;
     static_assert(CONST_PER_THREAD <= 2, "two named registers below");
@@ -141,7 +167,7 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     const float* const lb1n = lb3 + 2 * C + 4 * CI;
     const half_t* const lq = reinterpret_cast<const half_t*>(smem + OFF_Q);
     const half_t* const lq2 = lq + C;
-    unsigned tab = lds_base + OFF_TABLE + (lane & (R - 1)) * 16;
+    unsigned tab = lds_base + OFF_TABLE + (lane & (RT - 1)) * 16;
 
     // ---- the wave's weight streams (dcb_nsplit.hip pack_*8): waves 0 .. 3 first (their share may be the larger one),
     // then 4 .. 7; fragment f of a wave at 1 KB f from the wave's base, lane-linear. Buffer loads: lane offset + 12-bit
@@ -202,7 +228,8 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX * CH_I / NTHREADS + RING + NT_C * PXT * 2) : "memory");     // the constants have arrived
     {
         float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
-        t[tid] = tab0; t[tid + NTHREADS] = tab1;
+        if (RT == 4 || tid < WSILU_SEGMENTS) t[tid] = tab0;
+        if (RT == 4) t[tid + NTHREADS] = tab1;
         float* lb = reinterpret_cast<float*>(smem + OFF_BIAS);
         half_t* lqw = reinterpret_cast<half_t*>(smem + OFF_Q);
         auto put = [&](int k, const half8 v) {
@@ -231,7 +258,8 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     // ---- fragment addressing. Row of pixel tile t: (32 t + px) * pitch; chunk c of a row sits at c ^ (px & 15).
     // B fragment of k-slice ks: chunk 2 ks + hi = (2 ks) ^ hi: (32 ks) ^ s0 = ((32 (ks & 7)) ^ s0) + 256 (ks >> 3).
     int s0 = (hi ^ (px & 15)) << 4;
-    int rowA = px * PITCH_I, rowB = px * PITCH_C + OFF_B;     // byte offsets from smem
+    int rowA = px * PITCH_I, rowB = px * PITCH_C + OFF_B;     // byte offsets from smem (TRIPLE: rowA of the tile's own t2 buffer)
+    int abuf = 0;                                             // TRIPLE: byte offset of the buffer this tile's t2 / t live in (0 or OFF_A2)
     int hi4 = 4 * hi;
     int fa8[8], fb8[8];
     auto frag_a = [&](int t, int ks) { return *reinterpret_cast<const half8*>(smem + fa8[ks & 7] + (t * (32 * PITCH_I) + (ks >> 3) * 256)); };
@@ -336,6 +364,13 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
 #pragma unroll
                 for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb0, f0 + 32 * j);
             contract(std::integral_constant<int, TP>{}, KsC{}, std::integral_constant<int, F_DC3 + pass * TP * KS_C>{}, frag_b, acc);
+            if constexpr (TRIPLE && pass == NP - 1) {
+                // the next tile's t2 into the OTHER buffer and its x into registers, in front of an epilogue that needs no
+                // weights (the ring already holds ffn.2's first fragments: they return before these transfers)
+                if (has_next) dma_tile(ChI{}, p.t2, p.ldt, abuf == 0 ? OFF_A2 : 0, next_tile * PX);
+                if constexpr (NT_C > 0) load_x(next_tile * PX);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int t = 0; t < PXT; ++t) {
                 float sums[2][4];
@@ -346,7 +381,7 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
                         float4v c[GB];
 #pragma unroll
                         for (int e = 0; e < GB; ++e) {
-                            const float4 r = wsilu_row_lds<R, true>(acc[h][t][g0 + e], tab);
+                            const float4 r = wsilu_row_lds<RT, true>(acc[h][t][g0 + e], tab);
                             c[e] = float4v{r.x, r.y, r.z, r.w};
                         }
 #pragma unroll
@@ -389,9 +424,11 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         // the next tile's transfers: t is dead once every wave is behind its last ffn.2 MFMA. They go out in front of
         // the epilogue, which needs no weights (a transfer from memory in front of a contraction holds up every weight
         // fragment requested behind it: loads return in order)
-        __syncthreads();
-        if (has_next) dma_tile(ChI{}, p.t2, p.ldt, 0, next_tile * PX);
-        if constexpr (NT_C > 0) load_x(next_tile * PX);        // (unconditional - rows are clamped to the picture)
+        if constexpr (!TRIPLE) {
+            __syncthreads();
+            if (has_next) dma_tile(ChI{}, p.t2, p.ldt, 0, next_tile * PX);
+            if constexpr (NT_C > 0) load_x(next_tile * PX);        // (unconditional - rows are clamped to the picture)
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NT_C; ++j)
@@ -459,7 +496,7 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
                     float4v c[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float4 r = wsilu_row_lds<R, true>(v[e], tab);
+                        const float4 r = wsilu_row_lds<RT, true>(v[e], tab);
                         c[e] = float4v{r.x, r.y, r.z, r.w};
                     }
                     half8 o;
@@ -484,6 +521,10 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     __syncthreads();
     tile = next_tile;
     m0 = tile * PX;
+    if constexpr (TRIPLE) {
+        abuf = abuf == 0 ? OFF_A2 : 0;
+        rowA = pxv * PITCH_I + abuf;
+    }
     }       // tiles
     // stamp 31: the workgroup's last instruction (all tiles): shader cycles of the whole launch per workgroup; stamps 29 / 30: the
     // constant 100 MHz clock (s_memrealtime) at entry / here: cycles / time = the shader clock the launch really ran at
@@ -512,7 +553,7 @@ template <int C, int CI, int PXT, bool NEXT>
 void launch8(const NsParams& p, hipStream_t stream)
 {
     auto kern = dcb_nsplit8_kernel<C, CI, PXT, NEXT>;
-    constexpr int smem = nsplit::smem_bytes<C, CI, PXT>();
+    constexpr int smem = Lay<C, CI, PXT>::BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
     constexpr int MAX_DEVICES = 64;
     static std::once_flag once[MAX_DEVICES];
