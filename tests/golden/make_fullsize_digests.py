@@ -166,6 +166,10 @@ def cases(quick):
         c["ld_qends_1280x720"] = lambda: run_inter("ld", (720, 1280), [(0, 0), (63, 0), (0, 1)], 0.15)
         c["hts_qends_1280x720"] = lambda: run_inter("hts", (720, 1280), [(0, 0), (63, 0)], 0.15)
         c["htl_qends_1280x720"] = lambda: run_inter("htl", (720, 1280), [(0, 0), (63, 1)], 0.15)
+        # ... and the two remaining rate points bench.py cycles through
+        c["ld_qmid_1280x720"] = lambda: run_inter("ld", (720, 1280), [(16, 0), (48, 0)], 0.15)
+        c["hts_qmid_1280x720"] = lambda: run_inter("hts", (720, 1280), [(16, 0), (48, 0)], 0.15)
+        c["htl_qmid_1280x720"] = lambda: run_inter("htl", (720, 1280), [(16, 0), (48, 0)], 0.15)
         c["hts_3840x2160"] = lambda: run_inter("hts", (2160, 3840), [(32, 0)], 0.15)
         c["htl_3840x2160"] = lambda: run_inter("htl", (2160, 3840), [(32, 0)], 0.15)
     c["hts_1280x720"] = lambda: run_inter("hts", (720, 1280), [(32, 0), (45, 1)], 0.15)

@@ -219,3 +219,34 @@ class _Solo:
 def test_gather_needs_a_shape_when_the_collector_owns_nothing():
     with pytest.raises(ValueError, match="owns no picture"):
         sharding.gather_pictures({}, _Solo(), dst=2)
+
+
+class _TwoRanks:
+    def __init__(self, rank):
+        self.rank = rank
+
+    def get_world_size(self):
+        return 2
+
+    def get_rank(self):
+        return self.rank
+
+    def get_backend(self):
+        return "gloo"
+
+
+def test_gather_checks_that_the_pictures_belong_to_this_rank_for_the_given_src():
+    """advisor, round 3: gather_pictures needs the fan-out's `src`; a caller that forgets it (src 1, default 0) used to hang
+    or collect the wrong pictures - now the mismatch between what the rank holds and what it owns is an error up front"""
+    world = 2
+    mine_of_rank0_for_src1 = {i: torch.zeros(1) for i in range(8) if (sharding.head_owner(i, world) + 1) % world == 0}
+    with pytest.raises(ValueError, match="another src"):
+        sharding.gather_pictures(mine_of_rank0_for_src1, _TwoRanks(0), dst=0, src=0)
+
+
+def test_fanout_heads_context_restores_the_owner():
+    p = _FakeHT()
+    p.set_recon_mask(0)
+    with sharding.fanout_heads(p) as q:
+        assert q is p and p.mask == 0
+    assert p.mask == 0xFF
