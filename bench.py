@@ -784,7 +784,7 @@ def main():
                 if kind == args.workload:
                     continue
                 w = make_work(kind, height, width)
-                others[kind] = fps_block(w, 0, 36 if kind in ("hts", "htl") else 96, 12, with_roofline=not args.no_roofline)
+                others[kind] = fps_block(w, 0, 48 if kind in ("hts", "htl") else 96, 12, with_roofline=not args.no_roofline)
                 del w
                 torch.cuda.empty_cache()
             out["other_workloads"] = others
