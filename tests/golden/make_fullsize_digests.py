@@ -173,6 +173,16 @@ def cases(quick):
         c["hts_3840x2160"] = lambda: run_inter("hts", (2160, 3840), [(32, 0)], 0.15)
         c["htl_3840x2160"] = lambda: run_inter("htl", (2160, 3840), [(32, 0)], 0.15)
     c["hts_1280x720"] = lambda: run_inter("hts", (720, 1280), [(32, 0), (45, 1)], 0.15)
+    if not quick:
+        # round 5: where the coverage was thinnest - every inter model at 1920x1080 with the rate
+        # points at both ends of the range AND a memory reset, the intra model at 3840x2160 at q 0 and q 63, LD at
+        # 3840x2160 at q 0 / 63 with a reset
+        c["ld_qends_1920x1080"] = lambda: run_inter("ld", (1080, 1920), [(0, 0), (63, 1), (63, 0)], 0.15)
+        c["dmci_3840x2160_q63_t0.15"] = lambda: run_dmci((2160, 3840), 63, 0.15, decode=False)
+        c["hts_qends_1920x1080"] = lambda: run_inter("hts", (1080, 1920), [(0, 0), (63, 1)], 0.15)
+        c["dmci_3840x2160_q0_t0.15"] = lambda: run_dmci((2160, 3840), 0, 0.15, decode=False)
+        c["htl_qends_1920x1080"] = lambda: run_inter("htl", (1080, 1920), [(63, 0), (0, 1)], 0.15)
+        c["ld_qends_3840x2160"] = lambda: run_inter("ld", (2160, 3840), [(63, 0), (0, 1)], 0.15)
     return c
 
 

@@ -1,0 +1,107 @@
+"""Generates tests/golden/graph_psnr_fullsize.json from the REFERENCE Python model (run in the build container, where
+/root/reference exists): north_star's tolerance "within 0.02 dB PSNR on reconstructed frames" pinned at BASELINE's
+own picture size, not only on the 64x64 ... 128x64 fixtures of dmci_golden.npz.
+
+For 1920x1080 pictures at the five rate points bench.py cycles through (picture index = q index, the pictures of
+tests/golden/fullsize_digests.json's intra cases) the reference's fp32 graph
+``DMCI.forward_one_frame(x, qp, recon_only=True)`` (/root/reference/src/models/image_model.py:150-192, the only
+CPU-runnable reference path; ~25 s per picture on 8 cores) reconstructs the replicate-padded 1088x1920 picture; stored are
+the PSNR of that reconstruction (clamped to +-0.5 like every inference-path output, shuffle.cu:53-56) against the source
+over the visible 1080x1920 area - all three planes of the 4:4:4 working format together, and per plane -, the digest of
+the source picture (so a host that generates different synthetic data is recognised) and the graph's output statistics.
+tests/test_fullsize_gpu.py::test_intra_psnr_within_tolerance_of_the_fp32_graph compares the product's reconstruction of
+the same picture with these numbers on the GPU box.
+
+The skip mode has to be OFF for that comparison (skip_thres = -60000, as in tests/test_oracle_cpu.py): the training
+graph has none, and with seeded RANDOM weights about half of the predicted scales are <= 0, which the
+inference path's `scale * mask <= skip_thres` test (stream.cu:589-590) zeroes even at skip_thres = 0 - measured on the
+q 32 picture: 16.695 dB (skip_thres 0) against the graph's 16.382 dB, and 16.3818 dB against 16.3821 dB with the skip
+mode off. `--oracle` adds the bit-exact oracle's own result for the skip-free setting (sha256 of its reconstruction and
+bit stream, ~ 160 s of 8 cores per picture): one more full-size digest per rate point for the product to equal.
+
+Usage: python tests/golden/make_graph_psnr_golden.py [--oracle]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from dcvc_amd import arch, synthetic  # noqa: E402
+from oracle import build_oracle, rans as orc  # noqa: E402
+
+CASES = [(1080, 1920, qp) for qp in (0, 16, 32, 48, 63)]   # (H, W, qp = picture index); H + 8 = 17 * 64 fits the graph as it is
+SEED = 0
+SKIP_OFF = -60000.0
+OUT = os.path.join(ROOT, "tests", "golden", "graph_psnr_fullsize.json")
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float(10 * np.log10(1.0 / mse))
+
+
+def main():
+    from codec_util import picture
+    build_oracle.build_ref()
+    sys.path.insert(0, "/root/reference")
+    sys.modules["MLCodec_extensions_cpp"] = orc.load_ref()
+    from src.models.image_model import DMCI
+    torch.set_num_threads(os.cpu_count() or 8)
+    net = DMCI().eval()
+    net.load_state_dict(synthetic.synthetic_state_dict(arch.dmci_spec(), SEED), strict=True)
+    out = {}
+    if os.path.exists(OUT):
+        with open(OUT) as f:
+            out = json.load(f)
+    with_oracle = "--oracle" in sys.argv
+    with torch.no_grad():
+        for H, W, qp in CASES:
+            x = picture(H, W, index=qp)                             # fp16 [H, W, 3], what the codecs are fed
+            xt = torch.from_numpy(x.astype(np.float32)).permute(2, 0, 1).unsqueeze(0)
+            # the training graph needs multiples of 64 (three stride-2 stages behind the /8 unshuffle); the inference
+            # path pads to 16: 1080 -> 1088 = 17 * 64 is the same picture for both (720 -> 768 against 720 -> 720 would not be)
+            pb, pr = -H % 64, -W % 64
+            xp = torch.nn.functional.pad(xt, (0, pr, 0, pb), mode="replicate")
+            t = time.time()
+            x_hat = net.forward_one_frame(xp, torch.tensor([qp]), recon_only=True)
+            dt = time.time() - t
+            xh = x_hat[0].permute(1, 2, 0).numpy().clip(-0.5, 0.5)[:H, :W]
+            src = x.astype(np.float32)
+            name = "dmci_%dx%d_q%d_noskip" % (W, H, qp)
+            keep = {k: v for k, v in out.get(name, {}).items() if k.startswith("oracle_")}
+            out[name] = {
+                "height": H, "width": W, "qp": qp, "index": qp, "input": hashlib.sha256(x.tobytes()).hexdigest(),
+                "graph_padding": [pb, pr],
+                "psnr": psnr(xh, src), "psnr_planes": [psnr(xh[..., c], src[..., c]) for c in range(3)],
+                "x_hat_mean": float(xh.mean()), "x_hat_std": float(xh.std()), "graph_seconds": round(dt, 1),
+            }
+            out[name].update(keep)
+            if with_oracle and "oracle_x_hat" not in out[name]:
+                from codec_util import dmci_model, oracle_for
+                import copy
+                m = copy.deepcopy(dmci_model(skip_thres=0.15))      # the tables of fullsize_cdf.npz (skip_thres is not in them)
+                m.skip_thres = SKIP_OFF
+                o = oracle_for(m)
+                t = time.time()
+                r = o.compress(x, qp)
+                out[name].update(oracle_x_hat=hashlib.sha256(np.ascontiguousarray(r["x_hat"]).tobytes()).hexdigest(),
+                                 oracle_bit_stream=hashlib.sha256(r["bit_stream"]).hexdigest(), oracle_bytes=len(r["bit_stream"]),
+                                 oracle_ec_parallel=int(r["ec_parallel"]), oracle_psnr=psnr(r["x_hat"][:H, :W], src),
+                                 oracle_seconds=round(time.time() - t, 1))
+            print(name, out[name], flush=True)
+            with open(OUT, "w") as f:
+                json.dump(out, f, indent=1, sort_keys=True)
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

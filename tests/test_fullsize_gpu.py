@@ -106,6 +106,59 @@ def test_intra_matches_oracle_digest(name):
     assert sha(from_device_output(out["x_hat"])) == d["x_hat"], "decoder-side reconstruction"
 
 
+_GRAPH_PATH = os.path.join(os.path.dirname(_PATH), "graph_psnr_fullsize.json")
+with open(_GRAPH_PATH) as _f:
+    GRAPH = json.load(_f)
+SKIP_OFF = -60000.0             # below every scale an fp16 network can produce: the skip mode never fires
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float(10 * np.log10(1.0 / mse))
+
+
+@pytest.mark.parametrize("name", sorted(GRAPH))
+def test_intra_psnr_within_tolerance_of_the_fp32_graph(name):
+    """north_star's tolerance at BASELINE's picture size: the reconstruction's PSNR against the source is within
+    0.02 dB of the REFERENCE's fp32 graph `forward_one_frame(recon_only=True)` (image_model.py:150-192) on the same
+    1920x1080 picture and weights - numbers made by the imported reference itself (tests/golden/
+    make_graph_psnr_golden.py), the anchor that does not depend on this repo's model of the matrix cores. The skip mode
+    is off (the graph has none; see the generating script for what it does to random weights even at skip_thres 0).
+    Where the script stored the oracle's own skip-free result, reconstruction and bytes equal it bit for bit as well."""
+    d = GRAPH[name]
+    hw, qp = (d["height"], d["width"]), d["qp"]
+    m = _with_golden_tables(dmci_model(skip_thres=0.15), "dmci")
+    m.skip_thres = SKIP_OFF
+    x = picture(hw[0], hw[1], index=d["index"])
+    _same_inputs(d["input"], sha(x), "pictures")
+    g = _gpu_net(m)
+    pr, pb = g.get_padding_size(hw[0], hw[1], 16)
+    got = g.compress(to_device_input(x), qp, pb, pr)
+    torch.cuda.synchronize()
+    x_hat = from_device_output(got["x_hat"])
+    dec = _gpu_net(m)
+    out = dec.decompress(got["bit_stream"], {"height": hw[0], "width": hw[1]}, qp, got["ec_parallel"])
+    torch.cuda.synchronize()
+    assert np.array_equal(from_device_output(out["x_hat"]), x_hat), "decoder-side reconstruction"
+    src = x.astype(np.float32)
+    vis = x_hat[:hw[0], :hw[1]]
+    p = _psnr(vis, src)
+    planes = [_psnr(vis[..., c], src[..., c]) for c in range(3)]
+    print("%s: PSNR vs source %.4f dB (fp32 graph %.4f dB, delta %+.4f); planes %s vs %s; %d bytes" % (
+        name, p, d["psnr"], p - d["psnr"], ["%.4f" % v for v in planes], ["%.4f" % v for v in d["psnr_planes"]],
+        len(got["bit_stream"])))
+    assert abs(p - d["psnr"]) <= 0.02                       # the tolerance north_star states
+    for c in range(3):
+        assert abs(planes[c] - d["psnr_planes"][c]) <= 0.02, "plane %d" % c
+    # the reference's metric weights the planes (6 Y + U + V) / 8 (test_video.py:63-66)
+    w = lambda v: (6 * v[0] + v[1] + v[2]) / 8
+    assert abs(w(planes) - w(d["psnr_planes"])) <= 0.02
+    if "oracle_x_hat" in d:
+        assert sha(x_hat) == d["oracle_x_hat"], "reconstruction differs from the oracle's (skip mode off)"
+        assert got["ec_parallel"] == d["oracle_ec_parallel"] and len(got["bit_stream"]) == d["oracle_bytes"]
+        assert sha(got["bit_stream"]) == d["oracle_bit_stream"], "rANS bytes differ from the oracle's (skip mode off)"
+
+
 @pytest.mark.parametrize("name", _INTER)
 def test_inter_matches_oracle_digest(name):
     d = DIGESTS[name]
