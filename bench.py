@@ -13,15 +13,27 @@ One step = compress one picture to a real rANS bit stream + decompress it again 
 DMCI.decompress of the reference surface, host entropy coding included), pictures resident in HBM
 as fp16 NHWC tensors. Every rank codes its own pictures (independent units, no data-path collective);
 `value` = pictures/s of the whole job over the K timed steps (barrier + synchronize on both sides,
-max over ranks). --workload ld|hts|htl: configs[2] with the inter models (one step = one compress +
-one decompress call on separate encoder / decoder objects: 1 picture for LD, a chunk of 8 for HT).
+max over ranks) of the SEQUENTIAL loop: compress, then decompress, one call after the other from one thread, as the
+reference harness orders its calls (one codec object for the intra model). --workload ld|hts|htl: configs[2] with the
+inter models (one step = one compress + one decompress call on separate encoder / decoder objects: 1 picture for LD, a
+chunk of 8 for HT).
+
+Other modes:
+  --sweep64     BASELINE configs[4]: the full 64-point rate sweep at 3840x2160, rate points sharded over the ranks
+  --handoff K   ONE running GOP of an inter model whose temporal state moves to the next rank every K coded units
+                (RCCL point-to-point: north_star's context exchange); time / bytes per hand-off, bit-exact continuation
+  --fanout      ONE hierarchical stream, the 8 reconstruction heads of a chunk spread over the ranks
 
 The JSON line (rank 0) carries, besides the driver contract:
   encode_fps / decode_fps   SURVEY 8d's metric, measured the reference's way (test_video.py:261-265,
                             321-325, 380-388; test_compress_time.py:60-69): device synchronised, events
                             around every compress / decompress call, the first 4 calls dropped,
                             pictures per call / mean call time. A separate pass after the timed region.
-  other_workloads           the same three numbers for the other three models (short runs; N = 1 only)
+                            Also inside `config`.
+  pipelined                 an additional throughput mode, never `value`: encoder and decoder objects (their own, created with
+                            stream priorities) as a two-stage pipeline - an encoder thread codes picture i + 1 while the decoder
+                            thread decodes picture i (N = 1 only)
+  other_workloads           value / encode_fps / decode_fps / pipelined for the other three models (short runs; N = 1 only)
   roofline                  the DOMINANT contraction kernel (most time per step): its algorithmic FLOPs / the
                             HIP-event time of its launches, stamped live on the codec's stream by
                             hipExtLaunchKernelGGL in an extra eager pass; `all_contractions` = every contraction
@@ -30,11 +42,13 @@ The JSON line (rank 0) carries, besides the driver contract:
                             kernel sources changed since that pass)
   sustained                 the same loop run for >= --min-seconds after the K timed steps (the K-step region
                             of a short driver run is a fraction of a second)
-  uhd                       short 3840x2160 runs of all four workloads (BASELINE configs[4]'s resolution)
+  uhd                       short 3840x2160 runs of all four workloads (BASELINE configs[4]'s resolution) and `sweep64`: the
+                            64-point rate sweep as a short run (LD, 1 I + 2 P pictures per rate point, closure per rate point)
   cpu_baseline              the reference's CPU-runnable path (fp32 graph forward_one_frame, restated in
                             oracle/torch_graph.py) on this host: all cores = `value`, one thread beside it
-                            (the reference's set_torch_env pins 1, common.py:270), and the bit-exact
-                            oracle's compress + decompress; N = 1 only, bounded samples
+                            (the reference's set_torch_env pins 1, common.py:270), the bit-exact
+                            oracle's compress + decompress, and `psnr_vs_source`: the codec's PSNR on the picture the graph
+                            just reconstructed beside the graph's (north_star's 0.02 dB); N = 1 only, bounded samples
 """
 import argparse
 import contextlib
@@ -71,18 +85,30 @@ def parse_args():
     p.add_argument("--fanout", action="store_true",
                    help="hts / htl with --gpus N > 1: ONE stream, the 8 reconstruction heads of a chunk spread over the ranks "
                         "(feature_p broadcast over RCCL; strong scaling) instead of N independent streams")
-    p.add_argument("--one-codec", action="store_true",
-                   help="intra: ONE codec object codes and decodes, one call after the other (as the reference harness uses its "
-                        "i_frame_net). Default since round 4: separate encoder / decoder objects run as a two-stage pipeline")
-    p.add_argument("--two-codecs", action="store_true", help="(the default; kept for old command lines)")
+    p.add_argument("--sweep64", action="store_true",
+                   help="BASELINE configs[4]: the full 64-point rate sweep (q_index = linspace(0, 63, 64), test_video.py:512-514) at "
+                        "--resolution (default 3840x2160), rate points sharded over the ranks; --workload picks the model "
+                        "(intra: I pictures only; ld / hts / htl: 1 I picture + --sweep-units coded units per rate point)")
+    p.add_argument("--sweep-units", type=int, default=4, help="coded inter units per rate point of --sweep64")
+    p.add_argument("--handoff", type=int, default=0, metavar="K",
+                   help="ld / hts / htl: ONE running GOP whose temporal state moves to the next rank every K coded units "
+                        "(RCCL point-to-point; north_star's context exchange). Reports pictures/s, time and bytes per hand-off "
+                        "and whether the stream continued bit-exactly")
+    p.add_argument("--no-pipeline", action="store_true",
+                   help="skip the `pipelined` blocks (encoder and decoder objects as a two-stage pipeline on prioritised streams)")
+    p.add_argument("--one-codec", action="store_true", help="(the default since round 5; kept for old command lines)")
+    p.add_argument("--two-codecs", action="store_true", help="(kept for old command lines: the two-object loop is `pipelined`)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the short runs of the other three workloads")
-    p.add_argument("--resolution", default="%dx%d" % (WIDTH, HEIGHT), help="WxH of the synthetic pictures (3840x2160 = configs[4])")
+    p.add_argument("--resolution", default=None, help="WxH of the synthetic pictures (default 1920x1080; 3840x2160 = configs[4], "
+                                                      "the default of --sweep64)")
     p.add_argument("--no-uhd", action="store_true", help="skip the short 3840x2160 runs of the default line")
     p.add_argument("--min-seconds", type=float, default=2.0,
                    help="length of the `sustained` region behind the K timed steps (0 = none)")
     a = p.parse_args()
+    if a.resolution is None:
+        a.resolution = "3840x2160" if a.sweep64 else "%dx%d" % (WIDTH, HEIGHT)
     try:
         w, h = (int(v) for v in a.resolution.lower().split("x"))
         assert w > 0 and h > 0 and w % 2 == 0 and h % 2 == 0
@@ -137,22 +163,22 @@ def make_pictures(n, rank, device, height=HEIGHT, width=WIDTH):
 
 
 class IntraWorkload:
-    """configs[1]: every picture is an I picture. Default (round 4): a decoder object of its own (`dec_net`), driven as the
-    second stage of run_steps_overlapped() with its compute stream at high priority: the decoder's four host round trips per
-    picture (0.6 ms of idle GPU) are filled with the next picture's encoder kernels - 143.6 -> 148.1 pictures/s (sustained
-    150.0) on one box. The same two objects called one after the other from one thread are SLOWER than one object (125;
-    round 1 measured the same: 105.8 vs 119.6) - the decoder's short kernels queue behind the encoder's reconstruction tail at
-    equal priority. `--one-codec` (`dec_net=None`): one object codes and decodes, as the reference harness uses its i_frame_net."""
+    """configs[1]: every picture is an I picture. Default (`dec_net=None`): ONE codec object codes and decodes, one call
+    after the other, as the reference harness uses its i_frame_net (test_video.py:187,226,338) - this is the loop `value` is
+    measured on. `dec_net` + `prioritised`: a decoder object of its own with its compute stream at high priority, the second
+    stage of run_steps_overlapped() - the decoder's four host round trips per picture (0.6 ms of idle GPU) are filled with the
+    next picture's encoder kernels (reported as `pipelined`, never as `value`). The same two objects called one after the other
+    from one thread are SLOWER than one object (125 against 143 pictures/s: the decoder's short kernels queue behind the
+    encoder's reconstruction tail at equal priority)."""
     frames, kind = 1, "intra"
 
-    def __init__(self, gpu_net, pics, pad_b, pad_r, dec_net=None):
+    def __init__(self, gpu_net, pics, pad_b, pad_r, dec_net=None, prioritised=False):
         self.net, self.pics, self.pad_b, self.pad_r = gpu_net, pics, pad_b, pad_r
         self.dec = dec_net if dec_net is not None else gpu_net
         self.height, self.width = int(pics[0].shape[2]), int(pics[0].shape[3])
         self.sps = {"height": self.height, "width": self.width}
-        # --two-codecs: a decoder object of its own can run as the second stage of run_steps_overlapped()
-        self.overlapped = dec_net is not None
-        if self.overlapped and not os.environ.get("DCVC_BENCH_SEQUENTIAL") and os.environ.get("DCVC_BENCH_PRIORITIES", "1") != "0":
+        self.overlapped = dec_net is not None and prioritised
+        if self.overlapped and os.environ.get("DCVC_BENCH_PRIORITIES", "1") != "0":
             os.environ["DCVC_COMPUTE_PRIORITY"] = "high"
             self.dec._ensure_proxy()
             del os.environ["DCVC_COMPUTE_PRIORITY"]
@@ -191,9 +217,11 @@ class InterWorkload:
     (frame_idx + g_frame_delay) % reset_interval == 1 - every 32nd picture for LD, every 4th chunk for HT)."""
     RESET_INTERVAL = 32
 
-    def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r):
+    def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r, prioritised=False):
         from dcvc_amd import arch, models, synthetic
         self.kind, self.pad_b, self.pad_r = kind, pad_b, pad_r
+        # prioritised: the objects of the two-stage pipeline (`pipelined` in the JSON line); `value` is measured on plain ones
+        self.overlapped = prioritised
         self.height, self.width = int(pics[0].shape[2]), int(pics[0].shape[3])
         self.sps = {"height": self.height, "width": self.width}
         if kind == "ld":
@@ -206,7 +234,7 @@ class InterWorkload:
             self.frames, self.gop = 8, 12
         net.update(SKIP_THRES)
         self.enc, self.dec = _to_gpu(net, device), _to_gpu(net, device)
-        if self.overlapped and not os.environ.get("DCVC_BENCH_SEQUENTIAL") and os.environ.get("DCVC_BENCH_PRIORITIES", "1") != "0":
+        if self.overlapped and os.environ.get("DCVC_BENCH_PRIORITIES", "1") != "0":
             # the decoder's chain of short kernels and host round trips goes first, the encoder fills the gaps (the
             # priority of a codec's compute stream is read when the native object is created)
             for obj, prio in ((self.enc, "low"), (self.dec, "high")):
@@ -227,9 +255,8 @@ class InterWorkload:
         frame_idx = 1 + self.frames * (i % self.gop)
         return 1 if (frame_idx + self.frames) % self.RESET_INTERVAL == 1 else 0
 
-    # encoder and decoder are separate objects that share nothing but the bytes: run_steps_overlapped() drives them as a
-    # two-stage pipeline from two host threads (a real deployment runs them on different machines)
-    overlapped = True
+    # encoder and decoder are separate objects that share nothing but the bytes: with `prioritised` run_steps_overlapped()
+    # drives them as a two-stage pipeline from two host threads (a real deployment runs them on different machines)
 
     def prepare_enc(self, i):
         if i % self.gop == 0:
@@ -272,10 +299,8 @@ class FanoutWorkload(InterWorkload):
     decoder's entropy / prior / decoder stages, temporal state); it broadcasts feature_p over RCCL while its own
     reconstruction heads run, and every rank reconstructs its share of the 8 pictures
     (dcvc_amd/sharding.py decompress_fanout). Strong scaling: the work of a step does not grow with the number of GPUs."""
-    overlapped = False          # every rank takes part in every decompress call: one thread
-
     def __init__(self, kind, device, pics, gpu_intra, pad_b, pad_r, dist):
-        super().__init__(kind, device, pics, gpu_intra, pad_b, pad_r)
+        super().__init__(kind, device, pics, gpu_intra, pad_b, pad_r)      # (every rank takes part in every call: one thread)
         self.dist, self.rank = dist, dist.get_rank()
         if self.rank != 0:
             self.enc = None
@@ -366,11 +391,9 @@ def run_steps_overlapped(work, first, n, depth=int(os.environ.get("DCVC_BENCH_DE
 
 
 def step_loop(work):
-    """run_steps for one codec object / the fan-out, the two-stage pipeline for separate encoder / decoder objects
-    (DCVC_BENCH_SEQUENTIAL=1: always the plain loop - the A/B partner)"""
-    if getattr(work, "overlapped", False) and not os.environ.get("DCVC_BENCH_SEQUENTIAL"):
-        return run_steps_overlapped
-    return run_steps
+    """run_steps (one call after the other: the reference harness's loop) unless the workload's objects were created for
+    the two-stage pipeline (`prioritised`)"""
+    return run_steps_overlapped if getattr(work, "overlapped", False) else run_steps
 
 
 def call_times(work, first, n):
@@ -414,12 +437,44 @@ def box_identity(device):
         out["host_threads"] = len(names)
     except OSError:
         pass
+    # which sources: HEAD when this is a git checkout (the build container); on the GPU box the snapshot carries no .git,
+    # so __graft_entry__.build() leaves HEAD in .git_head whenever it runs inside a checkout - and, independent of either,
+    # a digest of the tracked sources that define the numbers (kernels, codecs, this file)
     try:
-        with open(os.path.join(ROOT, ".git_head")) as f:
-            out["commit"] = f.read().strip()
-    except OSError:
+        import subprocess
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10)
+        if head.returncode == 0 and head.stdout.strip():
+            out["commit"] = head.stdout.strip()
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                                   text=True, timeout=10)
+            out["commit_dirty"] = bool(dirty.stdout.strip())
+    except (OSError, subprocess.SubprocessError):
         pass
+    if "commit" not in out:
+        try:
+            with open(os.path.join(ROOT, ".git_head")) as f:
+                out["commit"] = f.read().strip()
+                out["commit_from"] = ".git_head (written by __graft_entry__.build() in the last git checkout it ran in)"
+        except OSError:
+            pass
+    out["source_digest"] = source_digest()
     return out
+
+
+def source_digest():
+    """sha256 over this file and every source under dcvc_amd/csrc + include (sorted by path): identifies the code that
+    produced a line whether or not a git checkout is around"""
+    import hashlib
+    h = hashlib.sha256()
+    paths = [os.path.join(ROOT, "bench.py")]
+    for top in ("dcvc_amd/csrc", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, top)):
+            paths += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".cpp"))]
+    for path in sorted(paths):
+        h.update(os.path.relpath(path, ROOT).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def closure_ok(work, first):
@@ -428,36 +483,66 @@ def closure_ok(work, first):
     return all([work.closure(first + k, qp) for k, qp in enumerate(QPS)])
 
 
-def fps_block(work, first, steps, warmup, with_roofline=False):
-    """throughput (pipelined loop) + the reference-style encode / decode rates of one workload"""
-    run_steps(work, first, warmup)           # (plain loop: graph capture of both objects from one thread)
-    loop = step_loop(work)
-    if loop is not run_steps:
-        loop(work, first + warmup, 2)        # the pipeline's own set-up outside the timed region
-        first += 2
+def timed_region(work, loop, first, steps):
+    """`steps` steps of `loop` between two device synchronisations -> (seconds, coded bytes)"""
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nbytes = loop(work, first + warmup, steps)
+    nbytes = loop(work, first, steps)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0, nbytes
+
+
+def pipelined_block(work, first, steps, warmup, min_seconds=0.0):
+    """The two-stage pipeline (run_steps_overlapped) on objects created for it (`prioritised`): an additional throughput
+    mode, reported beside `value`, never as `value`."""
+    run_steps(work, first, warmup)           # (plain loop: graph capture of both objects from one thread)
+    run_steps_overlapped(work, first + warmup, 2)        # the pipeline's own set-up outside the timed region
+    first += warmup + 2
+    dt, _ = timed_region(work, run_steps_overlapped, first, steps)
     first += steps
-    ncalls = min(steps, 24) + DROP_CALLS
-    te, td = call_times(work, first + warmup, ncalls)
     out = {"value": steps * work.frames / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
-           # (the plain loop is not measured on these objects: with the encoder's stream at low priority it runs slower than
-           # it does on unprioritised objects - DCVC_BENCH_SEQUENTIAL=1 python bench.py --workload W is the A/B partner)
-           "loop": "two-stage pipeline (encoder thread | decoder thread)" if loop is not run_steps else "one call after the other",
-           "encode_fps": work.frames / te, "decode_fps": work.frames / td,
-           "bpp": 8.0 * nbytes / steps / work.frames / (work.height * work.width),
-           "closure_ok": closure_ok(work, first + warmup + ncalls)}
-    if with_roofline:
-        r = roofline(work, n=2)
-        out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "all_contractions")}
+           "loop": "two-stage pipeline: an encoder thread codes step i + 1 while the decoder thread decodes step i (separate encoder / "
+                   "decoder objects, the decoder's compute stream at high priority, the encoder's at low)"}
+    if min_seconds > 0:
+        more = min(100 * steps, max(steps, int(np.ceil(1.15 * min_seconds * steps / max(dt, 1e-6)))))
+        t_more, _ = timed_region(work, run_steps_overlapped, first, more)
+        first += more
+        out["sustained"] = {"steps": more, "seconds": t_more, "value": more * work.frames / t_more, "unit": "frames/s"}
+    out["closure_ok"] = closure_ok(work, first)
     return out
 
 
-def cpu_baseline(cpu_net):
-    """The reference's CPU path (fp32 graph) and the bit-exact oracle on this host, bounded samples."""
+def fps_block(make, steps, warmup, with_roofline=False, with_pipeline=True):
+    """One workload as the default line's `other_workloads` / `uhd` report it: `value` = the plain loop (compress then
+    decompress, one call after the other, unprioritised objects - what the reference harness does), the reference-style
+    encode / decode rates, closure, roofline; `pipelined` = the two-stage loop on a second, prioritised set of objects."""
+    work = make(False)
+    run_steps(work, 0, warmup)
+    dt, nbytes = timed_region(work, run_steps, warmup, steps)
+    first = warmup + steps
+    ncalls = min(steps, 24) + DROP_CALLS
+    te, td = call_times(work, first, ncalls)
+    out = {"value": steps * work.frames / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "loop": "one call after the other (compress, then decompress)",
+           "encode_fps": work.frames / te, "decode_fps": work.frames / td,
+           "bpp": 8.0 * nbytes / steps / work.frames / (work.height * work.width),
+           "closure_ok": closure_ok(work, first + ncalls)}
+    if with_roofline:
+        r = roofline(work, n=2)
+        out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "all_contractions")}
+    del work
+    torch.cuda.empty_cache()
+    if with_pipeline:
+        work = make(True)
+        out["pipelined"] = pipelined_block(work, 0, steps, warmup)
+        del work
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(cpu_net, device):
+    """The reference's CPU path (fp32 graph) and the bit-exact oracle on this host, bounded samples - and, since the graph
+    reconstructs a whole 1088x1920 picture anyway, the product's PSNR on that very picture beside the graph's."""
     from oracle import codec, torch_graph
     from dcvc_amd import synthetic
     cores = os.cpu_count() or 1
@@ -469,8 +554,30 @@ def cpu_baseline(cpu_net):
     # crop, scaled by area
     tried = {t: torch_graph.time_forward(sd, 512, 512, 32, t) for t in sorted({min(cores, c) for c in (64, 32, 16)})}
     best = min(tried, key=tried.get)
-    t_all = torch_graph.time_forward(sd, 1088, 1920, 32, best)
+    # the picture: synthetic picture 32 at q 32 (the q-32 picture of tests/golden/graph_psnr_fullsize.json), replicate-padded
+    # 1080 -> 1088 as the inference path pads it
+    yy, uv = synthetic.synthetic_frame_yuv420(HEIGHT, WIDTH, 32, 0)
+    x16 = synthetic.yuv420_to_x(yy, uv).half()
+    xp = torch.nn.functional.pad(x16.float(), (0, 0, 0, -HEIGHT % 64), mode="replicate")
+    kept = []
+    t_all = torch_graph.time_forward(sd, xp.shape[2], xp.shape[3], 32, best, x=xp, keep=kept)
     t_one = torch_graph.time_forward(sd, 256, 256, 32, 1) * (1088 * 1920) / (256 * 256)
+
+    def psnr(a, b):
+        return float(10 * torch.log10(1.0 / torch.mean((a.double() - b.double()) ** 2)))
+    src = x16[:, :, :HEIGHT, :WIDTH].float()
+    graph_psnr = psnr(kept[0].clamp(-0.5, 0.5)[:, :, :HEIGHT, :WIDTH], src)
+    # the product on the same picture, skip mode off (the graph has none; tests/golden/make_graph_psnr_golden.py says what
+    # the skip mode does to RANDOM weights even at skip_thres 0)
+    import copy
+    m = copy.deepcopy(cpu_net)
+    m.skip_thres = -60000.0
+    g = _to_gpu(m, device)
+    pad_r, pad_b = g.get_padding_size(HEIGHT, WIDTH, 16)
+    r = g.compress(x16.to(device).contiguous(memory_format=torch.channels_last), 32, pad_b, pad_r)
+    torch.cuda.synchronize()
+    ours_psnr = psnr(r["x_hat"][:, :, :HEIGHT, :WIDTH].float().cpu(), src)
+    del g
     h = w = 160
     y, uv = synthetic.synthetic_frame_yuv420(h, w, 0, 0)
     x = synthetic.yuv420_to_x(y, uv)[0].permute(1, 2, 0).contiguous().numpy().astype(np.float16)
@@ -486,6 +593,11 @@ def cpu_baseline(cpu_net):
                   "on %d of %d hardware threads (fastest of %s on a 512x512 crop%s): %.2f s per picture"
                   % (best, cores, {t: round(v, 2) for t, v in tried.items()},
                      "; all 256 threads of the GPU box: 114 s for the crop, measured once" if cores > 64 else "", t_all),
+        "psnr_vs_source": {"fp32_graph": graph_psnr, "this_codec": ours_psnr, "delta_psnr_vs_fp32_graph": ours_psnr - graph_psnr,
+                           "tolerance": 0.02, "within_tolerance": abs(ours_psnr - graph_psnr) <= 0.02,
+                           "picture": "synthetic 1920x1080 picture 32 at q 32, skip mode off on the codec (the graph has none), "
+                                      "PSNR of the 4:4:4 working planes over the visible area; the reference's own graph on the "
+                                      "same picture: tests/golden/graph_psnr_fullsize.json"},
         "one_thread": {"value": 1.0 / t_one, "unit": "frames/s", "cores": 1,
                        "sample": "the same graph on 1 thread (the reference harness pins 1, common.py:270): one 256x256 crop, "
                                  "scaled by area to 1080p (%.1f s per picture)" % t_one},
@@ -614,6 +726,337 @@ def roofline(work, n=len(QPS)):
             "kernels": kernels}
 
 
+class BenchEnv:
+    """what every mode of main() needs"""
+
+    def __init__(self, args, rank, world, device, dist, comm_device, cpu_net, gpu_net, sync, max_over_ranks):
+        self.args, self.rank, self.world, self.device, self.dist, self.comm_device = args, rank, world, device, dist, comm_device
+        self.cpu_net, self.gpu_net, self.sync, self.max_over_ranks = cpu_net, gpu_net, sync, max_over_ranks
+
+
+def common_fields(env, fps, elapsed, steps, scaling, metric, config):
+    args = env.args
+    return {"metric": metric, "value": fps, "unit": "frames/s", "n_gpus": env.world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the reference architecture)",
+            "config": config, "box": box_identity(env.device)}
+
+
+def run_default(env, make_work):
+    """configs[1] / configs[2]: independent streams, one per rank (or --fanout: one hierarchical stream over all ranks)."""
+    args, rank, world, dist, device = env.args, env.rank, env.world, env.dist, env.device
+    height, width = args.height, args.width
+    fanout = args.fanout and world > 1
+    if args.fanout and args.workload not in ("hts", "htl"):
+        raise SystemExit("--fanout needs --workload hts or htl (the models with 8 reconstruction heads per call)")
+    if fanout:
+        pics = make_pictures(args.frames, rank, device, height, width)
+        pad_r, pad_b = env.gpu_net.get_padding_size(height, width, 16)
+        work = FanoutWorkload(args.workload, device, pics, env.gpu_net, pad_b, pad_r, dist)
+    else:
+        work = make_work(args.workload, height, width)
+    if os.environ.get("DCVC_BENCH_GRAPHS") in ("0", "1"):     # A/B of the codecs' launch mode (hipGraph replay / eager)
+        work.default_graphs = os.environ["DCVC_BENCH_GRAPHS"] == "1"
+        work.set_use_graphs(work.default_graphs)
+    # independent streams: rank r codes the steps shard_range() gives it out of world * steps (weak scaling,
+    # no data-path collective); fan-out: every rank takes part in every step
+    from dcvc_amd import sharding
+    mine = range(args.steps) if fanout else sharding.shard_range(world * args.steps, rank, world)
+    assert len(mine) == args.steps
+
+    # `value`: compress then decompress, one call after the other from one thread, no host synchronisation between steps -
+    # the reference harness's order of calls (test_video.py:224-265, 300-325) without its per-call synchronisation
+    run_steps(work, 0, args.warmup)
+    env.sync()
+    t0 = time.perf_counter()
+    nbytes = run_steps(work, args.warmup + mine.start, args.steps)
+    env.sync()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+
+    # the same loop for >= --min-seconds: the K-step region of a short driver run lasts a fraction of a second
+    sustained = None
+    if args.min_seconds > 0:
+        more = max(args.steps, int(np.ceil(1.15 * args.min_seconds * args.steps / max(elapsed, 1e-6))))      # (a margin: warm steps run faster)
+        more = min(more, 100 * args.steps)
+        env.sync()
+        t0 = time.perf_counter()
+        run_steps(work, args.warmup + mine.start + args.steps, more)
+        env.sync()
+        t_more = env.max_over_ranks(time.perf_counter() - t0)
+        sustained = {"steps": more, "seconds": t_more, "value": (1 if fanout else world) * more * work.frames / t_more,
+                     "unit": "frames/s"}
+
+    # step index behind everything this rank has coded so far (the inter workloads' GOP / reset cadence follows the index)
+    cursor = args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0)
+    ncalls = min(args.steps, 32) + DROP_CALLS
+    if fanout:       # every rank takes part in the per-call timing loop (the broadcast is a collective)
+        te, td = call_times(work, cursor, ncalls)
+    # every rank checks ITS codec objects after the timed regions (fan-out: the shared stream is checked by the tests)
+    closure = None if fanout else closure_ok(work, cursor + ncalls)
+    if dist is not None and closure is not None:
+        flag = torch.tensor([1.0 if closure else 0.0], dtype=torch.float64, device=env.comm_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        closure = bool(flag.item() > 0.5)
+    if rank != 0:
+        return None
+    if not fanout:
+        te, td = call_times(work, cursor, ncalls)
+    fps = (1 if fanout else world) * args.steps * work.frames / elapsed
+    res = "%dx%d" % (width, height)
+    one_object = args.workload == "intra"
+    loop_text = ("one call after the other from one thread: compress, then decompress (%s), no host synchronisation between steps"
+                 % ("ONE codec object codes and decodes, as the reference harness uses its i_frame_net" if one_object
+                    else "separate encoder / decoder objects, the decoder sees only the bytes"))
+    out = common_fields(
+        env, fps, elapsed, args.steps, "strong" if fanout else "weak",
+        "%s YUV420 %s encode+decode pictures per second (%s, real rANS bit streams, q_index in {0,16,32,48,63}; sequential loop: "
+        "compress then decompress per picture)" % ("1080p" if (height, width) == (1080, 1920) else res,
+                                                   "intra" if args.workload == "intra" else "inter", NAMES[args.workload]),
+        {"workload": ("%s " + res + " YUV420, ONE stream over all ranks (rank 0 codes, feature_p broadcast, reconstruction "
+                      "heads fanned out), " if fanout else "%s " + res + " YUV420 on 1xMI355X per rank, ") % NAMES[args.workload]
+                     + "q_index cycling {0,16,32,48,63}, skip_thres 0.15, one step = compress + decompress of %d "
+                       "picture(s)" % work.frames,
+         "sharding": "recon-head fan-out" if fanout else "independent streams (sharding.shard_range)",
+         "codec_objects": "one" if one_object else "separate encoder / decoder",
+         "loop": "sequential",
+         "pictures_per_step": work.frames, "resolution": res,
+         # the reference's own metric (BASELINE.json; test_video.py:261-265, 380-388), here so that it survives any
+         # filtering of top-level keys
+         "encode_fps": work.frames / te, "decode_fps": work.frames / td})
+    out.update({
+        "encode_fps": work.frames / te, "decode_fps": work.frames / td,
+        "avg_frame_encoding_time_ms": 1e3 * te / work.frames, "avg_frame_decoding_time_ms": 1e3 * td / work.frames,
+        "fps_method": "value: K steps of the sequential loop between device synchronisations; encode_fps / decode_fps: the "
+                      "reference's loop (events around each call on a synchronised device, first %d calls dropped, rank 0)" % DROP_CALLS,
+        "loop": loop_text,
+        "bytes_per_picture": nbytes / args.steps / work.frames,
+        "bpp": 8.0 * nbytes / args.steps / work.frames / (height * width),
+        "closure_ok": closure,
+    })
+    if sustained is not None:
+        out["sustained"] = sustained
+    if not args.no_roofline and not fanout:
+        out["roofline"] = roofline(work)
+    del work
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_pipeline:
+        wp = make_work(args.workload, height, width, prioritised=True)
+        out["pipelined"] = pipelined_block(wp, 0, args.steps, args.warmup, args.min_seconds)
+        del wp
+        torch.cuda.empty_cache()
+    if world == 1 and not args.no_extras:
+        others = {}
+        for kind in NAMES:
+            if kind == args.workload:
+                continue
+            others[kind] = fps_block(lambda pr, kind=kind: make_work(kind, height, width, prioritised=pr),
+                                     48 if kind in ("hts", "htl") else 96, 12, with_roofline=not args.no_roofline,
+                                     with_pipeline=not args.no_pipeline)
+        out["other_workloads"] = others
+        if not args.no_uhd and (height, width) == (HEIGHT, WIDTH):
+            uhd = {"resolution": "3840x2160"}
+            for kind in NAMES:
+                uhd[kind] = fps_block(lambda pr, kind=kind: make_work(kind, 2160, 3840, frames=2, prioritised=pr),
+                                      6 if kind in ("hts", "htl") else 12, 3, with_roofline=not args.no_roofline,
+                                      with_pipeline=False)
+            # BASELINE configs[4]: the 64-point rate sweep at 3840x2160, as a short run (1 I + 2 P pictures per rate point)
+            uhd["sweep64"] = sweep64_block(env, "ld", 2160, 3840, 2)
+            out["uhd"] = uhd
+    if world == 1 and not args.no_cpu_baseline and args.workload == "intra":
+        out["cpu_baseline"] = cpu_baseline(env.cpu_net, device)
+    return out
+
+
+def sweep64_block(env, kind, height, width, units):
+    """BASELINE configs[4] / test_video.py:512-514: q_index = linspace(0, 63, 64) - every one of the 64 rate points - at
+    `height` x `width`, sharded over the ranks by rate point (sharding.shard_range: the reference's own scaling mode is one
+    worker per (sequence, rate point), test_video.py:527-564). Per rate point: one I picture (intra codec, compress +
+    decompress) and, for an inter `kind`, `units` coded units of the inter model seeded from it (LD: pictures, HT: chunks of
+    8), each compress + decompress on separate encoder / decoder objects. closure is checked PER RATE POINT outside the
+    timed sections: the decoder's I picture equals the encoder's bit for bit, the inter decoder (bytes only) holds the
+    encoder's feature_p. Returns rank 0's report (None elsewhere)."""
+    from dcvc_amd import sharding
+    rank, world, dist, device = env.rank, env.world, env.dist, env.device
+    pics = make_pictures(2, 0, device, height, width)
+    pad_r, pad_b = env.gpu_net.get_padding_size(height, width, 16)
+    i_enc, i_dec = env.gpu_net, _to_gpu(env.cpu_net, device)
+    sps = {"height": height, "width": width}
+    inter = None if kind == "intra" else InterWorkload(kind, device, pics, env.gpu_net, pad_b, pad_r)
+    frames = 1 if inter is None else inter.frames
+    qps = [int(q) for q in np.linspace(0, 63, 64)]
+    assert qps == list(range(64))
+    mine = [qps[i] for i in sharding.shard_range(len(qps), rank, world)]
+
+    def rate_point(q):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = i_enc.compress(pics[0], q, pad_b, pad_r)
+        xi = r["x_hat"]
+        xd = i_dec.decompress(r["bit_stream"], sps, q, r["ec_parallel"])["x_hat"]
+        nbytes = [len(r["bit_stream"])]
+        if inter is not None:
+            inter.enc.add_ref_feature_from_frame(xi)
+            inter.dec.add_ref_feature_from_frame(xd, apply_feature_adaptor=False)
+            for u in range(units):
+                e = inter.enc.compress(inter.inputs[u % len(inter.inputs)], q, 0, pad_b, pad_r)
+                inter.dec.decompress(e["bit_stream"], sps, q, e["ec_parallel"], 0)
+                nbytes.append(len(e["bit_stream"]))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = bool(torch.equal(xi, xd)) and bool(torch.isfinite(xd.float()).all())
+        if inter is not None:
+            ok = ok and bool(np.array_equal(inter.enc._ensure_proxy().debug_read("feature_p", np.float16),
+                                            inter.dec._ensure_proxy().debug_read("feature_p", np.float16)))
+        return dt, nbytes, ok
+
+    for q in mine[:2]:            # untimed: graph capture of every stage
+        rate_point(q)
+    env.sync()
+    per_q, total = [], 0.0
+    for q in mine:
+        dt, nbytes, ok = rate_point(q)
+        total += dt
+        per_q.append({"q": q, "bytes_i": nbytes[0], "bytes_p": sum(nbytes[1:]), "closure_ok": ok})
+    elapsed = env.max_over_ranks(total)
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_q)
+        per_q = [e for part in gathered for e in part]
+    del inter, i_dec
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    per_q.sort(key=lambda e: e["q"])
+    pictures = len(qps) * (1 + (0 if kind == "intra" else units * frames))
+    bpp = [8.0 * (e["bytes_i"] + e["bytes_p"]) / (1 + (0 if kind == "intra" else units * frames)) / (height * width) for e in per_q]
+    return {"value": pictures / elapsed, "unit": "frames/s", "seconds": elapsed, "rate_points": len(per_q),
+            "pictures_per_rate_point": pictures // len(qps), "resolution": "%dx%d" % (width, height), "workload": kind,
+            "closure_ok": all(e["closure_ok"] for e in per_q) and [e["q"] for e in per_q] == qps,
+            "closure_ok_per_q": [e["closure_ok"] for e in per_q],
+            "bpp_per_q": [round(b, 4) for b in bpp],
+            "note": "q_index = linspace(0, 63, 64) (test_video.py:512-514); per rate point 1 I picture + %s, compress + "
+                    "decompress; rate points sharded over the ranks (sharding.shard_range); timed per rate point between device "
+                    "synchronisations, closure checked outside the timed sections"
+                    % ("nothing else" if kind == "intra" else "%d coded unit(s) of %d picture(s) of the %s model" % (units, frames, kind))}
+
+
+def run_sweep64(env, kind, units):
+    args = env.args
+    blk = sweep64_block(env, kind, args.height, args.width, units)
+    if env.rank != 0:
+        return None
+    res = "%dx%d" % (args.width, args.height)
+    out = common_fields(
+        env, blk["value"], blk["seconds"], blk["rate_points"], "strong",
+        "%s YUV420 full 64-point rate sweep, encode+decode pictures per second (%s, real rANS bit streams)" % (res, NAMES[kind]),
+        {"workload": "BASELINE configs[4]: %s %s YUV420, q_index = linspace(0, 63, 64), skip_thres 0.15, %d picture(s) per rate point, "
+                     "rate points sharded over %d rank(s)" % (NAMES[kind], res, blk["pictures_per_rate_point"], env.world),
+         "sharding": "rate points (sharding.shard_range)", "resolution": res, "loop": "sequential"})
+    out["steps_are"] = "rate points"
+    out["sweep64"] = blk
+    out["closure_ok"] = blk["closure_ok"]
+    return out
+
+
+def run_handoff(env, kind, every):
+    """north_star's "temporal context exchanged by RCCL point-to-point": ONE running GOP of an inter model whose coding moves
+    to the next rank every `every` coded units. The owner of unit i is rank (i // every) % world; at a boundary the owner
+    exports the temporal state of its encoder AND decoder objects (reference feature, memory, feature_p, context, temporal
+    prior: one flat tensor each) and sends both point-to-point (sharding.send_state / recv_state: RCCL over xGMI; host-staged
+    over gloo). Inside a GOP the recurrence is strictly sequential, so this buys placement (load balancing,
+    pre-emption), not speed: the line reports pictures/s of the ONE stream, the time and size of a hand-off, and - the point -
+    that the bytes of every coded unit equal those of the same stream coded on one rank without any hand-off."""
+    from dcvc_amd import sharding
+    args, rank, world, dist, device = env.args, env.rank, env.world, env.dist, env.device
+    if kind == "intra":
+        raise SystemExit("--handoff needs --workload ld, hts or htl (the intra codec has no temporal state)")
+    height, width = args.height, args.width
+    pics = make_pictures(args.frames, 0, device, height, width)          # every rank: the SAME pictures (one stream)
+    pad_r, pad_b = env.gpu_net.get_padding_size(height, width, 16)
+    work = InterWorkload(kind, device, pics, env.gpu_net, pad_b, pad_r)
+    total = args.warmup + args.steps
+    owner = lambda i: (i // every) % world
+    units, t_send, n_bytes = [], [], 0
+
+    def code(i):
+        qp = QPS[i % len(QPS)]
+        if i % work.gop == 0:
+            work.prepare(i)
+        enc = work.compress(i, qp)
+        work.decompress(i, qp, enc)
+        units.append((i, enc["bit_stream"]))
+
+    def span(first, last):
+        nonlocal n_bytes
+        for i in range(first, last):
+            if owner(i) == rank:
+                code(i)
+            if i + 1 < total and owner(i + 1) != owner(i) and world > 1:
+                if owner(i) == rank:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n = sharding.send_state(work.enc._ensure_proxy(), owner(i + 1), dist)
+                    n += sharding.send_state(work.dec._ensure_proxy(), owner(i + 1), dist)
+                    torch.cuda.synchronize()
+                    if i >= args.warmup:
+                        t_send.append(time.perf_counter() - t0)
+                    n_bytes = n
+                elif owner(i + 1) == rank:
+                    sharding.recv_state(work.enc._ensure_proxy(), owner(i), height, width, dist)
+                    sharding.recv_state(work.dec._ensure_proxy(), owner(i), height, width, dist)
+
+    span(0, args.warmup)
+    env.sync()
+    t0 = time.perf_counter()
+    span(args.warmup, total)
+    env.sync()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    coded = sharding.gather_units(units, dist)
+    stats = torch.tensor([sum(t_send), len(t_send), n_bytes], dtype=torch.float64, device=env.comm_device)
+    if dist is not None:
+        parts = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(parts, stats)
+        stats = torch.stack(parts).cpu()
+    else:
+        stats = stats.reshape(1, 3).cpu()
+    if rank != 0:
+        return None
+    # the same stream on ONE rank, fresh objects, no hand-off
+    ref = InterWorkload(kind, device, pics, env.gpu_net, pad_b, pad_r)
+    want = []
+    for i in range(total):
+        qp = QPS[i % len(QPS)]
+        ref.prepare(i)
+        enc = ref.compress(i, qp)
+        ref.decompress(i, qp, enc)
+        want.append(enc["bit_stream"])
+    torch.cuda.synchronize()
+    exact = len(coded) == total and all(bytes(a) == bytes(b) for a, b in zip(coded, want))
+    n_handoffs = int(stats[:, 1].sum().item())
+    res = "%dx%d" % (width, height)
+    out = common_fields(
+        env, args.steps * work.frames / elapsed, elapsed, args.steps, "strong",
+        "%s YUV420 inter encode+decode pictures per second of ONE running GOP handed from GPU to GPU every %d coded unit(s) (%s, "
+        "real rANS bit streams)" % ("1080p" if (height, width) == (1080, 1920) else res, every, NAMES[kind]),
+        {"workload": "%s %s YUV420, ONE stream over %d rank(s): the temporal state of encoder and decoder moves to the next rank every "
+                     "%d coded unit(s) of %d picture(s) (point-to-point, sharding.send_state / recv_state), q_index cycling "
+                     "{0,16,32,48,63}, skip_thres 0.15" % (NAMES[kind], res, world, every, work.frames),
+         "sharding": "GOP hand-off (temporal state point-to-point)", "resolution": res, "loop": "sequential",
+         "pictures_per_step": work.frames})
+    out["handoff"] = {
+        "every_units": every, "count": n_handoffs,
+        "us_per_handoff": 1e6 * float(stats[:, 0].sum().item()) / n_handoffs if n_handoffs else None,
+        "bytes_per_handoff": int(stats[:, 2].max().item()),
+        "gb_per_s": (float(stats[:, 2].max().item()) * n_handoffs / float(stats[:, 0].sum().item()) / 1e9) if n_handoffs else None,
+        "timing": "sender side: synchronise, export + send encoder state, export + send decoder state, synchronise",
+        "backend": dist.get_backend() if dist is not None else None,
+        "bit_exact_continuation": exact,
+        "checked": "the bytes of all %d coded units (warm-up included) against the same stream coded on rank 0 alone" % total}
+    out["closure_ok"] = exact
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -650,30 +1093,12 @@ def main():
     height, width = args.height, args.width
     cpu_net, gpu_net = build_model(device)
 
-    def make_work(kind, h, w, frames=args.frames):
+    def make_work(kind, h, w, frames=args.frames, prioritised=False):
         pics = make_pictures(frames, rank, device, h, w)
         pad_r, pad_b = gpu_net.get_padding_size(h, w, 16)
         if kind == "intra":
-            return IntraWorkload(gpu_net, pics, pad_b, pad_r, None if args.one_codec else _to_gpu(cpu_net, device))
-        return InterWorkload(kind, device, pics, gpu_net, pad_b, pad_r)
-
-    fanout = args.fanout and world > 1
-    if args.fanout and args.workload not in ("hts", "htl"):
-        raise SystemExit("--fanout needs --workload hts or htl (the models with 8 reconstruction heads per call)")
-    if fanout:
-        pics = make_pictures(args.frames, rank, device, height, width)
-        pad_r, pad_b = gpu_net.get_padding_size(height, width, 16)
-        work = FanoutWorkload(args.workload, device, pics, gpu_net, pad_b, pad_r, dist)
-    else:
-        work = make_work(args.workload, height, width)
-    if os.environ.get("DCVC_BENCH_GRAPHS") in ("0", "1"):     # A/B of the codecs' launch mode (hipGraph replay / eager)
-        work.default_graphs = os.environ["DCVC_BENCH_GRAPHS"] == "1"
-        work.set_use_graphs(work.default_graphs)
-    # independent streams: rank r codes the steps shard_range() gives it out of world * steps (weak scaling,
-    # no data-path collective); fan-out: every rank takes part in every step
-    from dcvc_amd import sharding
-    mine = range(args.steps) if fanout else sharding.shard_range(world * args.steps, rank, world)
-    assert len(mine) == args.steps
+            return IntraWorkload(gpu_net, pics, pad_b, pad_r, _to_gpu(cpu_net, device) if prioritised else None, prioritised)
+        return InterWorkload(kind, device, pics, gpu_net, pad_b, pad_r, prioritised)
 
     def sync():
         if dist is not None:
@@ -687,117 +1112,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    run_steps(work, 0, args.warmup)          # (plain loop: the codecs capture their graphs from one thread)
-    loop = step_loop(work)
-    if loop is not run_steps:
-        # two more untimed steps through the pipeline itself: the encoder thread's stream and the first hand-overs between
-        # the two threads are set up outside the timed region (they cost ~ 7 ms of a 20-step region otherwise)
-        loop(work, args.warmup, 2)
-        mine = range(mine.start + 2, mine.stop + 2)
-    sync()
-    t0 = time.perf_counter()
-    nbytes = loop(work, args.warmup + mine.start, args.steps)
-    sync()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-
-    # the same loop for >= --min-seconds: the K-step region of a short driver run lasts a fraction of a second
-    sustained = None
-    if args.min_seconds > 0:
-        more = max(args.steps, int(np.ceil(1.15 * args.min_seconds * args.steps / max(elapsed, 1e-6))))      # (a margin: warm steps run faster)
-        more = min(more, 100 * args.steps)
-        sync()
-        t0 = time.perf_counter()
-        loop(work, args.warmup + mine.start + args.steps, more)
-        sync()
-        t_more = max_over_ranks(time.perf_counter() - t0)
-        sustained = {"steps": more, "seconds": t_more, "value": (1 if fanout else world) * more * work.frames / t_more,
-                     "unit": "frames/s"}
-
-    # step index behind everything this rank has coded so far (the inter workloads' GOP / reset cadence follows the index)
-    cursor = args.warmup + mine.start + args.steps + (sustained or {}).get("steps", 0)
-    # beside the two-stage pipeline (rank 0, short, intra): ONE codec object coding and decoding, as the reference harness does.
-    # (Inter models: DCVC_BENCH_SEQUENTIAL=1 is the A/B partner - on objects whose streams carry priorities the plain loop
-    # runs slower than it does without them.)
-    plain = None
-    if rank == 0 and loop is not run_steps and args.workload == "intra":
-        n_plain = min(args.steps, 30)
-        w_plain = IntraWorkload(work.net, work.pics, work.pad_b, work.pad_r, None)
-        run_steps(w_plain, cursor, 4)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(w_plain, cursor + 4, n_plain)
-        torch.cuda.synchronize()
-        plain = {"value": n_plain * work.frames / (time.perf_counter() - t0), "unit": "frames/s (this rank)", "steps": n_plain,
-                 "loop": "one codec object, compress then decompress (the reference harness's way)"}
-    ncalls = min(args.steps, 32) + DROP_CALLS
-    if fanout:       # every rank takes part in the per-call timing loop (the broadcast is a collective)
-        te, td = call_times(work, cursor, ncalls)
-    # every rank checks ITS codec objects after the timed regions (fan-out: the shared stream is checked by the tests)
-    closure = None if fanout else closure_ok(work, cursor + ncalls)
-    if dist is not None and closure is not None:
-        flag = torch.tensor([1.0 if closure else 0.0], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        closure = bool(flag.item() > 0.5)
-    if rank == 0:
-        if not fanout:
-            te, td = call_times(work, cursor, ncalls)
-        fps = (1 if fanout else world) * args.steps * work.frames / elapsed
-        res = "%dx%d" % (width, height)
-        out = {
-            "metric": "%s YUV420 %s encode+decode pictures per second (%s, real rANS bit streams, q_index in {0,16,32,48,63})"
-                      % ("1080p" if (height, width) == (1080, 1920) else res, "intra" if args.workload == "intra" else "inter",
-                         NAMES[args.workload]),
-            "value": fps, "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong" if fanout else "weak", "vs_baseline": None, "dtype": "f16",
-            "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the reference architecture)",
-            "config": {"workload": ("%s " + res + " YUV420, ONE stream over all ranks (rank 0 codes, feature_p broadcast, reconstruction "
-                                    "heads fanned out), " if fanout else "%s " + res + " YUV420 on 1xMI355X per rank, ") % NAMES[args.workload]
-                                   + "q_index cycling {0,16,32,48,63}, skip_thres 0.15, one step = compress + decompress of %d "
-                                     "picture(s)" % work.frames,
-                       "sharding": "recon-head fan-out" if fanout else "independent streams (sharding.shard_range)",
-                       "codec_objects": "one" if (args.workload == "intra" and args.one_codec) else "separate encoder / decoder",
-                       "pictures_per_step": work.frames, "resolution": res},
-            "encode_fps": work.frames / te, "decode_fps": work.frames / td,
-            "avg_frame_encoding_time_ms": 1e3 * te / work.frames, "avg_frame_decoding_time_ms": 1e3 * td / work.frames,
-            "fps_method": "value: K pipelined steps between device synchronisations; encode_fps / decode_fps: the reference's loop "
-                          "(events around each call on a synchronised device, first %d calls dropped, rank 0)" % DROP_CALLS,
-            "loop": "two-stage pipeline: an encoder thread codes step i + 1 while the decoder thread decodes step i (separate "
-                    "encoder / decoder objects; DCVC_BENCH_SEQUENTIAL=1 = one call after the other)" if loop is not run_steps
-                    else "one call after the other (one codec object codes and decodes)",
-            "bytes_per_picture": nbytes / args.steps / work.frames,
-            "bpp": 8.0 * nbytes / args.steps / work.frames / (height * width),
-            "closure_ok": closure,
-            "box": box_identity(device),
-        }
-        if sustained is not None:
-            out["sustained"] = sustained
-        if plain is not None:
-            out["plain_loop"] = plain
-        if not args.no_roofline and not fanout:
-            out["roofline"] = roofline(work)
-        if world == 1 and not args.no_extras:
-            del work
-            torch.cuda.empty_cache()
-            others = {}
-            for kind in NAMES:
-                if kind == args.workload:
-                    continue
-                w = make_work(kind, height, width)
-                others[kind] = fps_block(w, 0, 48 if kind in ("hts", "htl") else 96, 12, with_roofline=not args.no_roofline)
-                del w
-                torch.cuda.empty_cache()
-            out["other_workloads"] = others
-            if not args.no_uhd and (height, width) == (HEIGHT, WIDTH):
-                uhd = {"resolution": "3840x2160"}
-                for kind in NAMES:
-                    w = make_work(kind, 2160, 3840, frames=2)
-                    uhd[kind] = fps_block(w, 0, 6 if kind in ("hts", "htl") else 12, 3, with_roofline=not args.no_roofline)
-                    del w
-                    torch.cuda.empty_cache()
-                out["uhd"] = uhd
-        if world == 1 and not args.no_cpu_baseline and args.workload == "intra":
-            out["cpu_baseline"] = cpu_baseline(cpu_net)
+    env = BenchEnv(args, rank, world, device, dist, comm_device, cpu_net, gpu_net, sync, max_over_ranks)
+    if args.sweep64:
+        out = run_sweep64(env, args.workload, args.sweep_units)
+    elif args.handoff > 0:
+        out = run_handoff(env, args.workload, args.handoff)
+    else:
+        out = run_default(env, make_work)
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -112,6 +112,10 @@ def head_mask(rank, world):
     return sum(1 << i for i in range(8) if head_owner(i, world) == rank)
 
 
+def _has_gpu():
+    return torch.cuda.is_available() and torch.cuda.device_count() > 0
+
+
 def _to_wire(t, dist):
     """a tensor as the backend can carry it: device tensors over RCCL, host tensors over gloo (which has no
     point-to-point for device memory) - the latter also on a GPU box (bench.py's gloo mode, tests)"""
@@ -156,7 +160,7 @@ def decompress_fanout(proxy, bit_stream, qp, height, width, ec_parallel, reset, 
                 pass
         feature = cache[1]
         dist.broadcast(feature, src)
-        if not feature.is_cuda and torch.cuda.is_available():
+        if not feature.is_cuda and _has_gpu():
             feature = feature.cuda()             # gloo on a GPU box: the transfer went through host memory
         proxy.import_feature(feature, height, width)
         out = proxy.run_recon_heads(mask, height, width)
@@ -229,17 +233,30 @@ def gather_pictures(mine, dist, dst=0, src=0, shape=None, dtype=torch.float16, d
 # uint8 device tensor (reference feature, memory, last decoded feature, context, temporal prior:
 # 84 MB at 1080p), which moves point-to-point over xGMI with backend "nccl" (= RCCL).
 def send_state(proxy, dst, dist):
-    state = proxy.export_state()
-    dev = state.device
-    dist.send(torch.tensor([state.numel()], dtype=torch.int64, device=dev), dst)
+    """-> bytes sent. Device tensors over RCCL; staged through host memory where the backend has no device
+    point-to-point (gloo on a GPU box: bench.py's one-device rehearsal, tests) - `_to_wire`, like the fan-out."""
+    state = _to_wire(proxy.export_state(), dist)
+    dist.send(torch.tensor([state.numel()], dtype=torch.int64, device=state.device), dst)
     dist.send(state, dst)
+    return state.numel()
 
 
 def recv_state(proxy, src, height, width, dist, device=None):
     dev = device if device is not None else _device_for(dist)
     n = torch.zeros(1, dtype=torch.int64, device=dev)
     dist.recv(n, src)
-    state = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    # one receive buffer per proxy and size (a hand-off every few pictures would otherwise allocate 84 MB each time)
+    key = (int(n.item()), str(dev))
+    cache = getattr(proxy, "_state_rx", None)
+    if cache is None or cache[0] != key:
+        cache = (key, torch.empty(key[0], dtype=torch.uint8, device=dev))
+        try:
+            proxy._state_rx = cache
+        except AttributeError:
+            pass
+    state = cache[1]
     dist.recv(state, src)
+    if not state.is_cuda and _has_gpu():
+        state = state.cuda()                     # gloo on a GPU box: the transfer went through host memory
     proxy.import_state(state, height, width)
     return state.numel()

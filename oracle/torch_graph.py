@@ -112,20 +112,25 @@ def forward_one_frame(sd, x, qp):
     return F.pixel_shuffle(out, 8)
 
 
-def time_forward(sd, height, width, qp, threads, repeats=1):
-    """seconds per picture of forward_one_frame on `threads` host threads (fp32, channels_last)."""
+def time_forward(sd, height, width, qp, threads, repeats=1, x=None, keep=None):
+    """seconds per picture of forward_one_frame on `threads` host threads (fp32, channels_last). `x`: the picture to
+    reconstruct ([1, 3, height, width] fp32; default seeded uniform noise); `keep`: a list that receives the last x_hat."""
     import time
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
-        g = torch.Generator().manual_seed(0)
-        x = (torch.rand((1, 3, height, width), generator=g) - 0.5).contiguous(memory_format=torch.channels_last)
+        if x is None:
+            g = torch.Generator().manual_seed(0)
+            x = torch.rand((1, 3, height, width), generator=g) - 0.5
+        x = x.contiguous(memory_format=torch.channels_last)
         sd32 = {k: (v.float().contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v.float())
                 for k, v in sd.items() if hasattr(v, "dim")}
         forward_one_frame(sd32, x[:, :, :64, :64], qp)          # warm-up (thread pool, kernels)
         t0 = time.perf_counter()
         for _ in range(repeats):
-            forward_one_frame(sd32, x, qp)
+            out = forward_one_frame(sd32, x, qp)
+        if keep is not None:
+            keep.append(out)
         return (time.perf_counter() - t0) / repeats
     finally:
         torch.set_num_threads(prev)
