@@ -11,6 +11,7 @@ import concurrent.futures
 import glob
 import hashlib
 import os
+import shutil
 import subprocess
 import sys
 
@@ -57,10 +58,40 @@ def _hipcc():
 
 
 def _host_cxx():
-    for cand in (os.environ.get("CXX"), "/opt/rocm/lib/llvm/bin/clang++", "g++"):
-        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+    """Compiler for the host-only translation units (.cpp): the clang++ that belongs to the hipcc in use - its sibling
+    ../lib/llvm/bin/clang++, or $ROCM_PATH - so that a ROCm outside /opt/rocm builds too. DCVC_HOST_CXX overrides (NOT
+    the generic $CXX: a conda or distro g++ exported there would silently replace the compiler); g++ is the last resort
+    and gets the GNU flag set (_host_flags)."""
+    cands = [os.environ.get("DCVC_HOST_CXX")]
+    hipcc = shutil.which(_hipcc()) or _hipcc()
+    if os.path.isabs(hipcc):
+        root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin", "clang++"), os.path.join(root, "llvm", "bin", "clang++")]
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin", "clang++"))
+    cands += ["/opt/rocm/lib/llvm/bin/clang++", "g++"]
+    for cand in cands:
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand) and shutil.which(cand)):
             return cand
     return "g++"
+
+
+_CLANG_ONLY = ("-fno-slp-vectorize", "-Wno-inline-asm")
+
+
+def _is_gnu(cxx):
+    try:
+        out = subprocess.run([cxx, "--version"], capture_output=True, text=True, timeout=20).stdout.lower()
+    except (OSError, subprocess.SubprocessError):
+        return False
+    return "clang" not in out and ("g++" in out or "gcc" in out or "free software foundation" in out)
+
+
+def _host_flags(cxx):
+    """COMMON for a host compiler: a GNU compiler rejects the clang-only switches ('unrecognized command-line option')"""
+    if _is_gnu(cxx):
+        return [f for f in COMMON if f not in _CLANG_ONLY] + ["-fno-tree-slp-vectorize"]
+    return list(COMMON)
 
 
 def _compile(src, obj, verbose):
@@ -71,7 +102,8 @@ def _compile(src, obj, verbose):
     else:
         # host-only C++ straight through clang++ (the hipcc wrapper would compile a .cpp as HIP, device pass included:
         # x86 target attributes and builtins - the AVX-512 path of the rANS decoder - do not exist there)
-        cmd = [_host_cxx(), "-c"] + COMMON
+        cxx = _host_cxx()
+        cmd = [cxx, "-c"] + _host_flags(cxx)
     cmd += ["-o", obj, src]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -85,7 +117,8 @@ def _compile(src, obj, verbose):
 
 def _digest(paths):
     # flags with the checkout location factored out: the tree is copied to another path on the GPU box
-    h = hashlib.sha256(" ".join(COMMON + HIP_FLAGS).replace(ROOT, "<root>").encode())
+    # (the host compiler is part of the digest: a library built with another one is not "current")
+    h = hashlib.sha256(" ".join(COMMON + HIP_FLAGS + [os.path.basename(_host_cxx())]).replace(ROOT, "<root>").encode())
     for p in sorted(paths):
         h.update(os.path.relpath(p, ROOT).encode())
         with open(p, "rb") as f:

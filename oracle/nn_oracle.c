@@ -33,6 +33,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------ fp16 <-> fp32 */
 static inline float half_to_float(uint16_t h)
@@ -506,6 +509,29 @@ static void conv1x1_epilogue(const float* v, int p, const uint16_t* r1, int ldr1
     }
 }
 
+/* Threads for a loop of `work` independent items in chunks of `grain`: never more than there are chunks, and never
+ * more than ORACLE_THREADS (environment; default 32). The GPU box's host has 256 hardware threads on two sockets: a team
+ * of 256 woken for the 64 pixels of a 64x64 test picture, thousands of times per picture, made the small live-oracle
+ * tests 5x slower there than on the 8-core build container (measured in round 5). */
+static int orc_threads(int64_t work, int grain)
+{
+#ifdef _OPENMP
+    static int cap = 0;
+    int64_t n = (work + grain - 1) / grain;
+    if (cap == 0) {
+        const char* e = getenv("ORACLE_THREADS");
+        int c = e ? atoi(e) : 32;
+        int m = omp_get_max_threads();
+        cap = c < 1 ? 1 : (c > m ? m : c);
+    }
+    return (int)(n < 1 ? 1 : (n > cap ? cap : n));
+#else
+    (void)work;
+    (void)grain;
+    return 1;
+#endif
+}
+
 /* x [P][ldx] (first K channels), w [N][K], bias [N] or NULL, r1/r2 [P][ld] or NULL,
  * q [Nout] or NULL (fused, before rounding), q2 [Nout] or NULL (fp16 multiply after rounding),
  * y [P][ldy]. K % 16 == 0. */
@@ -527,7 +553,7 @@ void orc_conv1x1(const uint16_t* x, int ldx, const uint16_t* w, const uint16_t* 
                 split_planes(w[(size_t)n * K + k], &wm[(size_t)k * N + n], &we[(size_t)k * N + n]);
             }
         }
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(orc_threads(P, 8))
         for (p = 0; p < P; p++) {
             int32_t* xm = (int32_t*)malloc(sizeof(int32_t) * (size_t)K * 2);
             int32_t* xe = xm + K;
@@ -558,7 +584,7 @@ void orc_conv1x1(const uint16_t* x, int ldx, const uint16_t* w, const uint16_t* 
     for (i = 0; i < (int64_t)N * K; i++) {
         ws[i] = split_half(w[i]);
     }
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(orc_threads(P, 8))
     for (p = 0; p < P; p++) {
         hparts* xs = (hparts*)malloc(sizeof(hparts) * (size_t)K);
         float* v = (float*)malloc(sizeof(float) * (size_t)N);
@@ -594,7 +620,7 @@ void orc_dwconv3x3(const uint16_t* x, int ldx, const uint16_t* wt, uint16_t* y, 
                    int W, int C)
 {
     int h;
-#pragma omp parallel for
+#pragma omp parallel for num_threads(orc_threads(H, 1))
     for (h = 0; h < H; h++) {
         int w, c, ky, kx;
         for (w = 0; w < W; w++) {

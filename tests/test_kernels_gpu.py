@@ -4,6 +4,7 @@ Dense convolutions are checked against a plain PyTorch fp32 reference of the sam
 inputs, fp32 math, one rounding) within a 1-2 fp16-ulp tolerance; integer / layout / symbol
 kernels are checked bit-exactly against the numpy oracle (oracle/symbols_np.py)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -148,7 +149,8 @@ def test_tconv2x2(ops):
     assert np.array_equal(y.cpu().numpy(), nn.subpel_conv1x1(nhwc(x).cpu().numpy(), w.cpu().numpy()))
 
 
-@pytest.mark.parametrize("H,W,C", [(17, 30, 384), (5, 7, 64), (68, 120, 256)])
+@pytest.mark.parametrize("H,W,C", [(17, 30, 384), (5, 7, 64), (68, 120, 256), (136, 240, 384), (13, 9, 128), (6, 3, 8), (8, 2, 64),
+                                   (1, 1, 8), (7, 64, 16), (45, 80, 128)])
 def test_dwconv3x3(ops, H, W, C):
     from gpu_util import call, ptr, stream, nhwc
     dev = "cuda"
@@ -162,6 +164,47 @@ def test_dwconv3x3(ops, H, W, C):
     _close(y, nhwc(want), "dwconv3x3", rtol=1e-3, atol=1e-3)
     from oracle import nn
     assert np.array_equal(y.cpu().numpy(), nn.dwconv3x3(nhwc(x).cpu().numpy(), w.cpu().numpy()))
+    # strided input / output rows (the codecs pass channel-slice views) give the same numbers
+    xs = torch.zeros((H, W, C + 24), dtype=torch.half, device=dev)
+    xs[:, :, 8:8 + C] = nhwc(x)
+    ys = torch.zeros((H, W, C + 40), dtype=torch.half, device=dev)
+    call(ops.dwconv3x3, ctypes.c_void_p(xs.data_ptr() + 16), C + 24, ptr(wt), ctypes.c_void_p(ys.data_ptr() + 32), C + 40, H, W, C, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(ys[:, :, 16:16 + C], y) and float(ys[:, :, :16].abs().max()) == 0 and float(ys[:, :, 16 + C:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("mode", ["sliding", "ahead"])
+def test_dwconv3x3_other_modes(mode):
+    """the round-1 sliding-window kernel and the default-register-budget form of the load-ahead kernel (DCVC_DWCONV_MODE,
+    read once per process): same arithmetic, same bits; prints the launch time of all three forms at 1080p / 8"""
+    import subprocess
+    import sys
+    env = dict(os.environ, DCVC_DWCONV_MODE=mode)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "test_dwconv3x3 and not other_modes", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "10 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]
+
+
+def test_dwconv3x3_launch_time(ops):
+    """not an assertion on speed - a record: microseconds per launch at (136 x 240, 384 channels) = 25 MB in, 25 MB out"""
+    from gpu_util import call, ptr, stream
+    dev = "cuda"
+    H, W, C = 136, 240, 384
+    x = _rand((H, W, C), 1.0, 33).to(dev)
+    wt = _rand((9, C), 0.3, 34).to(dev)
+    y = torch.zeros((H, W, C), dtype=torch.half, device=dev)
+    for _ in range(5):
+        call(ops.dwconv3x3, ptr(x), C, ptr(wt), ptr(y), C, H, W, C, stream())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        call(ops.dwconv3x3, ptr(x), C, ptr(wt), ptr(y), C, H, W, C, stream())
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 200
+    print("dwconv3x3 %s: %.2f us per launch, %.2f TB/s of the 50.1 MB a launch has to move" % (
+        os.environ.get("DCVC_DWCONV_MODE", "deep (default)"), us, 2 * H * W * C * 2 / us / 1e6))
 
 
 def test_layout_kernels_exact(ops):
