@@ -148,10 +148,38 @@ namespace {
 //                            weight POINTER: a caller that rewrote its weights in place, or whose allocator handed the same
 //                            address out again, silently got the old weights - advisor, round 3.)
 //   dcvc_dcb_nsplit_pack / _packed / _free   explicit handle for callers that launch many times (tools/probes/core_bench).
+// Device buffers of the entry points below, released on every path out (advisor, round 4: a throwing pack launch leaked them).
+// Stream-ordered temporaries (hipMallocAsync / hipFreeAsync on the caller's stream) or plain allocations of a device.
+struct AsyncBuf {
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    AsyncBuf(size_t bytes, hipStream_t stream) : st(stream) { dcvc::hip_check(hipMallocAsync(&p, bytes, st), "hipMallocAsync(packed weights)"); }
+    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, st); }
+    AsyncBuf(const AsyncBuf&) = delete;
+    AsyncBuf& operator=(const AsyncBuf&) = delete;
+    dcvc::half_t* half() const { return static_cast<dcvc::half_t*>(p); }
+};
+
 struct NsplitPacked {
     int c = 0, ci = 0, device = 0;
     dcvc::half_t* main = nullptr;
     dcvc::half_t* next = nullptr;
+    hipEvent_t packed = nullptr;          // recorded behind the pack launches: dcvc_dcb_nsplit_packed on ANOTHER stream waits for it
+    NsplitPacked() = default;
+    NsplitPacked(const NsplitPacked&) = delete;
+    NsplitPacked& operator=(const NsplitPacked&) = delete;
+    ~NsplitPacked()
+    {
+        // on the device that owns the buffers, behind every launch that may still read them
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        if (have && cur != device) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        if (main) (void)hipFree(main);
+        if (next) (void)hipFree(next);
+        if (packed) (void)hipEventDestroy(packed);
+        if (have && cur != device) (void)hipSetDevice(cur);
+    }
 };
 
 void nsplit_check_shape(int c, int ci)
@@ -186,24 +214,16 @@ int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void*
         nsplit_check_shape(c, ci);
         if (!w3 || !w0 || !w2) throw std::invalid_argument("dcb_nsplit: missing operand");
         hipStream_t st = S(stream);
-        void* wmain = nullptr;
-        void* wnext = nullptr;
-        dcvc::hip_check(hipMallocAsync(&wmain, dcvc::dcb_nsplit_main_halves(c, ci) * 2, st), "hipMallocAsync(packed weights)");
-        dcvc::dcb_nsplit_pack_main(H(w3), H(w0), H(w2), c, ci, static_cast<dcvc::half_t*>(wmain), st);
+        // packed copies live exactly as long as this call's launches: stream-ordered temporaries, freed on every path out
+        const AsyncBuf wmain(dcvc::dcb_nsplit_main_halves(c, ci) * 2, st);
+        dcvc::dcb_nsplit_pack_main(H(w3), H(w0), H(w2), c, ci, wmain.half(), st);
+        std::unique_ptr<AsyncBuf> wnext;
         if (w1n != nullptr) {
-            dcvc::hip_check(hipMallocAsync(&wnext, dcvc::dcb_nsplit_dc0_halves(c, ci) * 2, st), "hipMallocAsync(packed weights)");
-            dcvc::dcb_nsplit_pack_dc0(H(w1n), c, ci, static_cast<dcvc::half_t*>(wnext), st);
+            wnext = std::make_unique<AsyncBuf>(dcvc::dcb_nsplit_dc0_halves(c, ci) * 2, st);
+            dcvc::dcb_nsplit_pack_dc0(H(w1n), c, ci, wnext->half(), st);
         }
-        try {
-            nsplit_launch(static_cast<dcvc::half_t*>(wmain), static_cast<dcvc::half_t*>(wnext), t2, ldt, x, ldx, b3, b0, b2, q, q2, b1n,
-                          t1n, ldt1, y, ldy, pixels, c, ci, shortcut, st);
-        } catch (...) {
-            (void)hipFreeAsync(wmain, st);
-            if (wnext) (void)hipFreeAsync(wnext, st);
-            throw;
-        }
-        dcvc::hip_check(hipFreeAsync(wmain, st), "hipFreeAsync(packed weights)");
-        if (wnext) dcvc::hip_check(hipFreeAsync(wnext, st), "hipFreeAsync(packed weights)");
+        nsplit_launch(wmain.half(), wnext ? wnext->half() : nullptr, t2, ldt, x, ldx, b3, b0, b2, q, q2, b1n, t1n, ldt1, y, ldy,
+                      pixels, c, ci, shortcut, st);
     });
 }
 
@@ -213,7 +233,7 @@ int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const v
         dcvc::kernels_init();
         nsplit_check_shape(c, ci);
         if (!w3 || !w0 || !w2 || !handle) throw std::invalid_argument("dcb_nsplit_pack: missing operand");
-        auto pk = std::make_unique<NsplitPacked>();
+        auto pk = std::make_unique<NsplitPacked>();          // its destructor frees whatever has been allocated when a step below throws
         pk->c = c; pk->ci = ci;
         dcvc::hip_check(hipGetDevice(&pk->device), "hipGetDevice");
         void* m = nullptr;
@@ -222,13 +242,12 @@ int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const v
         dcvc::dcb_nsplit_pack_main(H(w3), H(w0), H(w2), c, ci, pk->main, S(stream));
         if (w1n != nullptr) {
             void* n = nullptr;
-            if (hipMalloc(&n, dcvc::dcb_nsplit_dc0_halves(c, ci) * 2) != hipSuccess) {
-                (void)hipFree(m);
-                throw std::runtime_error("hipMalloc(packed weights)");
-            }
+            dcvc::hip_check(hipMalloc(&n, dcvc::dcb_nsplit_dc0_halves(c, ci) * 2), "hipMalloc(packed weights)");
             pk->next = static_cast<dcvc::half_t*>(n);
             dcvc::dcb_nsplit_pack_dc0(H(w1n), c, ci, pk->next, S(stream));
         }
+        dcvc::hip_check(hipEventCreateWithFlags(&pk->packed, hipEventDisableTiming), "hipEventCreate");
+        dcvc::hip_check(hipEventRecord(pk->packed, S(stream)), "hipEventRecord(packed)");
         *handle = pk.release();
     });
 }
@@ -237,10 +256,8 @@ int dcvc_dcb_nsplit_free(void* handle)
 {
     return dcvc::guarded([&] {
         if (handle == nullptr) return;
+        // ~NsplitPacked: synchronises the OWNING device (not whichever is current), then frees
         std::unique_ptr<NsplitPacked> pk(static_cast<NsplitPacked*>(handle));
-        dcvc::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");      // launches that still read the packed copies
-        (void)hipFree(pk->main);
-        if (pk->next) (void)hipFree(pk->next);
     });
 }
 
@@ -256,6 +273,8 @@ int dcvc_dcb_nsplit_packed(const void* handle, const void* t2, int ldt, const vo
         dcvc::hip_check(hipGetDevice(&dev), "hipGetDevice");
         if (dev != pk->device) throw std::invalid_argument("dcb_nsplit_packed: the handle was packed on another device");
         if (with_next && pk->next == nullptr) throw std::invalid_argument("dcb_nsplit_packed: packed without the next block's dc.0");
+        // the pack launches ran on the stream given to _pack: any other stream orders itself behind them here
+        dcvc::hip_check(hipStreamWaitEvent(S(stream), pk->packed, 0), "hipStreamWaitEvent(packed)");
         nsplit_launch(pk->main, with_next ? pk->next : nullptr, t2, ldt, x, ldx, b3, b0, b2, q, q2, b1n, t1n, ldt1, y, ldy, pixels,
                       pk->c, pk->ci, shortcut, S(stream));
     });

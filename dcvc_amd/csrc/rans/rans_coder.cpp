@@ -172,7 +172,8 @@ inline int8_t dec_symbol(DecState& s, const CdfTable& t, int cdf_idx)
 // 2^16 becomes 0xFFFF, which no 16-bit cum exceeds): value = number of j >= 1 with cdf[j] <= cum = popcount of ONE
 // unsigned compare - no scan loop and, above all, no data-dependent loop exit to mispredict (the exit of the scan above
 // is close to a coin flip per symbol on spread distributions). The row's address depends on the index stream only, so
-// its load runs ahead of the serial state chain. Same arithmetic, same bytes: tests/test_rans.py runs both paths.
+// its load runs ahead of the serial state chain. Same arithmetic, same bytes: tests/test_rans.py decodes the golden streams
+// in child processes with DCVC_RANS_AVX512=0 and =1 (test_both_cdf_search_paths).
 #define DCVC_RANS_AVX512 1
 __attribute__((target("avx512f,avx512bw,popcnt"))) inline int search_avx512(const uint16_t* edge_row, uint32_t cum)
 {
@@ -300,7 +301,20 @@ void CdfTable::load(const int32_t* cdfs, int num_cdf, int row_stride, const int3
     }
     // AVX-512 search rows (see search_avx512): 32 x u16 per CDF, 64-byte aligned
     edge.clear();
-    if (stride <= kEdgeRow + 1 && kRansProbBits == 16 && cpu_has_avx512bw()) {
+    // The vector search counts j >= 1 with cdf[j] - 1 < cum (16-bit): it equals the scan only for rows that rise
+    // monotonically from cdf[0] = 0 with cdf[j] >= 1 for j >= 1 - a zero there (a leading zero-frequency symbol) would wrap
+    // to 0xFFFF and never be counted, while the scan counts it (advisor, round 4). The reference's tables are of that form
+    // (pmf_to_quantized_cdf gives every symbol a frequency >= 1); a table that is not keeps the portable search.
+    bool vector_ok = stride <= kEdgeRow + 1 && kRansProbBits == 16 && cpu_has_avx512bw();
+    for (int i = 0; vector_ok && i < num; ++i) {
+        const uint32_t* row = cdf.data() + static_cast<size_t>(i) * stride;
+        const int size = cdf_sizes[i];
+        if (size < 2 || size > stride || row[0] != 0) vector_ok = false;
+        for (int j = 1; vector_ok && j < size; ++j) {
+            if (row[j] == 0 || row[j] < row[j - 1] || row[j] > (1u << kRansProbBits)) vector_ok = false;
+        }
+    }
+    if (vector_ok) {
         edge.assign(static_cast<size_t>(num) * kEdgeRow, 0xFFFFu);
         for (int i = 0; i < num; ++i) {
             const uint32_t* row = cdf.data() + static_cast<size_t>(i) * stride;

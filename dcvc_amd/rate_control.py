@@ -76,7 +76,10 @@ class TargetBpp:
             # Only the budget it leaves moves qp, measured against the last P unit if there is one.
             if self._last is None:
                 return
-            per_picture = 2.0 ** self._last[1]
+            # ... projected to the q_index the controller stands at NOW: the last P unit was coded at self._last[0], and the
+            # update behind it has already moved self.qp - comparing its raw size again would correct the same error twice
+            # (advisor, round 4: q saw-toothed between 0 and 12 with intra period 32 in a simulation)
+            per_picture = 2.0 ** (self._last[1] + self.slope * (self.qp - self._last[0]))
         step = (math.log2(want) - math.log2(per_picture)) / self.slope
         self.qp += min(self.max_step, max(-self.max_step, step))           # bounded step: no oscillation with the intra period
         self.qp = min(float(self.qp_max), max(float(self.qp_min), self.qp))

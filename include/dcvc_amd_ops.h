@@ -94,8 +94,9 @@ int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void*
                     const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
                     int pixels, int c, int ci, int shortcut, void* stream);
 /* Handle form: pack w3 | w0 | w2 (and w1n, or NULL) once - the packed copies are a snapshot of the weights at pack time -,
- * launch any number of times, free (synchronises the device). with_next != 0 runs the next block's dc.0 inside the launch
- * (the handle must have been packed with w1n). No reference counterpart: the reference's CUTLASS kernels read the
+ * launch any number of times, free (synchronises the device the handle was packed on, whichever is current). `stream` of
+ * _pack and of _packed may differ: _packed orders its stream behind the pack launches (an event recorded by _pack).
+ * with_next != 0 runs the next block's dc.0 inside the launch (the handle must have been packed with w1n). No reference counterpart: the reference's CUTLASS kernels read the
  * row-major matrices directly. */
 int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const void* w1n, int c, int ci, void* stream,
                          void** handle);

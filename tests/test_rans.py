@@ -157,6 +157,56 @@ def test_against_compiled_reference_if_present(golden):
         assert np.array_equal(np.array(e.get_encoded_stream()), _product_encode(golden, n, comb, z))
 
 
+@pytest.mark.parametrize("avx512", ["0", "1"])
+def test_both_cdf_search_paths(avx512):
+    """The decoder's CDF search has a portable form (start table + scan) and an AVX-512 form (one compare + popcount);
+    which one runs is decided once per process (host capability, DCVC_RANS_AVX512=0 forces the portable one). Every
+    decode test of this file again in a child process with the switch at 0 and at 1: on an AVX-512 host both forms see
+    the golden vectors, elsewhere the portable form runs twice."""
+    import subprocess
+    import sys
+    if os.environ.get("DCVC_RANS_CHILD"):
+        pytest.skip("already in the child process")
+    env = dict(os.environ, DCVC_RANS_AVX512=avx512, DCVC_RANS_CHILD="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                          "decode_round_trip or extreme_symbols or reference_golden or zero_frequency"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]
+
+
+def test_zero_frequency_leading_symbol_decodes_the_same_on_both_paths():
+    """A CDF row with cdf[1] == 0 (symbol 0 has frequency 0) is outside what the vector search can represent (cdf[j] - 1
+    wraps): CdfTable::load must keep the portable search for such a table, so a stream coded with it decodes to the
+    symbols that went in whatever the host."""
+    y_cdf = np.zeros((2, 8), np.int32)
+    y_cdf[0, :6] = [0, 0, 20000, 50000, 65535, 65536]          # symbol 0 never occurs, 4 coded values + the escape slot
+    y_cdf[1, :5] = [0, 30000, 60000, 65535, 65536]
+    y_len = np.array([6, 5], np.int32)
+    z_cdf = np.zeros((128, 4), np.int32)
+    z_cdf[:, :4] = [0, 30000, 65535, 65536]
+    z_len = np.full(128, 4, np.int32)
+    rng = np.random.default_rng(3)
+    # values whose interleaved code (0, +1, -1, +2, ...) is >= 1 for table 0: never the zero-frequency symbol
+    sym = rng.choice(np.array([1, -1, 2], np.int16), size=4000)
+    idx = np.zeros(4000, np.int16)
+    comb = ((sym << 8) + idx).astype(np.int16)
+    e = mine.RansEncoder()
+    e.set_cdf(z_cdf, z_len, 0)
+    e.set_cdf(y_cdf, y_len, 1)
+    e.reset()
+    e.set_entropy_coder_parallel(1)
+    e.encode_y(comb)
+    e.flush()
+    s = np.array(e.get_encoded_stream())
+    d = mine.RansDecoder()
+    d.set_cdf(z_cdf, z_len, 0)
+    d.set_cdf(y_cdf, y_len, 1)
+    d.set_entropy_coder_parallel(1)
+    d.set_stream(s)
+    d.decode_y(idx.astype(np.uint8))
+    assert np.array_equal(d.get_decoded_tensor(), sym.astype(np.int8))
+
+
 def test_errors_are_reported():
     e = mine.RansEncoder()
     with pytest.raises(RuntimeError):

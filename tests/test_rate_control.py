@@ -107,3 +107,29 @@ def test_an_intra_picture_does_not_kick_the_controller():
     steps = [abs(qps[k + 1] - qps[k]) for k in range(len(units) - 1) if not kinds[k] and not kinds[k + 1]]
     assert max(steps) <= c.max_step + 1
     assert abs(c.spent_bits_per_picture / pixels - target) / target < 0.2
+
+
+def test_the_update_behind_an_intra_picture_projects_the_last_p_unit_to_the_current_q_index():
+    """advisor, round 4: behind an I picture the controller compares the budget with the last P unit's size - which was
+    measured at THAT unit's q_index, while the update behind the P unit has already moved the controller. Comparing the raw
+    size again corrects the same error twice; the size is projected along the model's slope to the q_index the controller
+    stands at now."""
+    import math
+    pixels = 1920 * 1080
+    c = rc.TargetBpp(0.05, pixels, qp0=30, horizon=8)
+    p_bits = 4.0 * c.target_bits                      # a P picture four times over budget at q 30
+    assert c.next_qp(False) == 30
+    c.update(p_bits, 1, False)
+    q_after_p = c.qp
+    assert q_after_p == 30 - c.max_step              # the bounded step down
+    spent, pictures = c.spent, c.pictures
+    i_bits = 10.0 * c.target_bits
+    c.update(i_bits, 1, True)
+    budget = c.target_bits * (pictures + 1 + c.horizon) - (spent + i_bits)
+    want = max(budget / c.horizon, c.target_bits / 64.0)
+    projected = math.log2(p_bits) + c.slope * (q_after_p - 30)
+    step = (math.log2(want) - projected) / c.slope
+    assert c.qp == pytest.approx(min(63.0, max(0.0, q_after_p + min(c.max_step, max(-c.max_step, step)))))
+    # and the projection matters: against the raw size the step would have been larger by (q_after_p - 30) model steps
+    raw_step = (math.log2(want) - math.log2(p_bits)) / c.slope
+    assert raw_step == pytest.approx(step + (q_after_p - 30))
