@@ -637,7 +637,7 @@ def pmc_traffic(kernel):
         return None, "no PMC pass on file (%s)" % type(e).__name__
 
 
-KERNEL_NAMES = {0: "conv_gemm_kernel", 1: "dcb_core_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "dcb_nsplit_kernel",
+KERNEL_NAMES = {0: "conv_gemm_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "dcb_nsplit_kernel",
                 5: "dcb_nsplit8_kernel"}
 
 
@@ -661,9 +661,9 @@ def roofline(work, n=len(QPS)):
     _lib.check(en(0))
     work.set_use_graphs(work.default_graphs)
     flops = 2.0 * buf["M"].astype(np.float64) * buf["N"] * buf["K"]
-    # variant bits 28..31: the kernel family of the launch (ops.h GemmLaunchInfo); 8 = dcb_core (the sign bit)
+    # variant bits 28..31: the kernel family of the launch (ops.h GemmLaunchInfo)
     fam = (buf["variant"].astype(np.int64) >> 28) & 0xF
-    family = np.where(fam >= 8, 1, fam)
+    family = fam
     if os.environ.get("DCVC_BENCH_SHAPES"):
         agg = {}
         for r, f in zip(buf, flops):
@@ -686,10 +686,6 @@ def roofline(work, n=len(QPS)):
         return {"kernel": name, "launches_per_step": cnt / n, "avg_launch_us": 1e3 * ms / cnt, "ms_per_step": ms / n,
                 "gflop_per_step": fl / n / 1e9, "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                 "algorithmic_bytes_per_launch": alg_bytes}
-    # algorithmic bytes per launch (every operand once). dcb_core: the depthwise output and the block input
-    # in, the block output and the next block's dc.0 output out ([P8][384] fp16 each) + 2.06 MB of weights
-    P8 = ((work.height + 15) // 16 * 2) * ((work.width + 15) // 16 * 2)
-    core_bytes = 4 * P8 * 384 * 2 + 7 * 384 * 384 * 2
     kernels = []
     for f, name in KERNEL_NAMES.items():
         sel = family == f
@@ -710,7 +706,7 @@ def roofline(work, n=len(QPS)):
                     k["with_next_dc0"] = nxt
                     kernels.append(k)
             continue
-        k = part(sel, name, core_bytes if f == 1 else None)
+        k = part(sel, name, None)
         if k:
             kernels.append(k)
     total_ms, total_fl = float(buf["ms"].sum()), float(flops.sum())

@@ -38,9 +38,7 @@ def _sources():
     srcs = []
     for pat in ("*.cpp", "*.hip", "*/*.cpp", "*/*.hip"):
         srcs += glob.glob(os.path.join(CSRC, pat))
-    # round 2's block kernel (dcb_core.hip, 1 000 lines of straight-line code) only on request; its stand-in otherwise
-    skip = "dcb_core_off.hip" if "-DDCVC_WITH_DCB_CORE" in os.environ.get("DCVC_EXTRA_DEFS", "") else "dcb_core.hip"
-    return sorted(s for s in srcs if os.sep + "_obj" not in s and os.sep + "cli" + os.sep not in s and os.path.basename(s) != skip)
+    return sorted(s for s in srcs if os.sep + "_obj" not in s and os.sep + "cli" + os.sep not in s)
 
 
 def _headers():

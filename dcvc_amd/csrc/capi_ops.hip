@@ -124,22 +124,6 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
     });
 }
 
-int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
-                  const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
-                  const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
-                  int pixels, int c, int shortcut, void* stream)
-{
-    return dcvc::guarded([&] {
-        dcvc::kernels_init();
-        dcvc::DcbCoreDesc d;
-        d.t2 = H(t2); d.ldt = ldt; d.x = H(x); d.ldx = ldx; d.w3 = H(w3); d.b3 = H(b3);
-        d.w0 = H(w0); d.b0 = H(b0); d.w2 = H(w2); d.b2 = H(b2); d.q = H(q); d.q2 = H(q2);
-        d.w1n = H(w1n); d.b1n = H(b1n); d.t1n = H(t1n); d.ldt1 = ldt1; d.y = H(y); d.ldy = ldy;
-        d.pixels = pixels; d.c = c; d.shortcut = shortcut != 0;
-        dcvc::dcb_core(d, S(stream));
-    });
-}
-
 namespace {
 // The N-split kernel wants its per-wave fragment streams, not the reference's row-major matrices. The codecs pack once
 // at set_param time (dcvc::DcbW::load). The operator-level entry points below serve tests and tools:
@@ -384,11 +368,6 @@ int dcvc_gemm_timeline_buffer(void* device_buffer)
 int dcvc_dcb_nsplit_timeline_buffer(void* device_buffer)
 {
     return dcvc::guarded([&] { dcvc::dcb_nsplit_timeline_buffer(static_cast<long long*>(device_buffer)); });
-}
-
-int dcvc_dcb_core_timeline_buffer(void* device_buffer)
-{
-    return dcvc::guarded([&] { dcvc::dcb_core_timeline_buffer(static_cast<long long*>(device_buffer)); });
 }
 
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream)

@@ -97,14 +97,14 @@ struct DcbW {
     // [pixels][c] buffer for the adaptor output; with it (or without an adaptor) and y != x the
     // half-width blocks of the inter models run as ONE launch (kernels/dcb_tail.hip reads the block
     // input of neighbouring patches, so it cannot run in place)
-    // Full-width blocks (c = 384) run everything behind the depthwise conv in one launch
-    // (kernels/dcb_core.hip), which can also compute dc.0 of the block that FOLLOWS in a chain:
+    // Blocks whose shape the N-split kernel has (kernels/dcb_nsplit.hip) run everything behind the depthwise conv in one
+    // launch, which can also compute dc.0 of the block that FOLLOWS in a chain:
     // `next` = that block (must satisfy feeds(next)), its dc.0 output then waits in s.t1 and the
     // caller passes dc0_done = true to next->forward().
     void forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut = false,
                  const half_t* q_fused = nullptr, const half_t* q_after = nullptr, View alt = View(),
                  const DcbW* next = nullptr, bool dc0_done = false) const;
-    bool core_fused() const;                     // this block runs through dcb_core / dcb_nsplit
+    bool core_fused() const;                     // this block runs through dcb_nsplit
     bool nsplit() const { return packed_main != nullptr; }
     bool feeds(const DcbW& next) const;          // ... and can compute next's dc.0 on the way out
 };

@@ -171,7 +171,7 @@ void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
 
 bool DcbW::core_fused() const
 {
-    return nsplit() || (dcb_core_supported(c, cdc, cffn) && dc0.b && dc3.b && ffn0.b && ffn2.b);
+    return nsplit();
 }
 
 bool DcbW::feeds(const DcbW& next) const
@@ -235,18 +235,6 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
             d.wnext = next->packed_dc0; d.b1n = next->dc0.b; d.t1n = s.t1; d.ldt1 = next->cdc;
         }
         dcb_nsplit(d, st);
-        return;
-    }
-    if (core_fused()) {
-        // dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) in one launch, intermediates in registers
-        DcbCoreDesc d;
-        d.t2 = s.t2; d.ldt = cdc; d.x = in.p; d.ldx = in.ld;
-        d.w3 = dc3.w; d.b3 = dc3.b; d.w0 = ffn0.w; d.b0 = ffn0.b; d.w2 = ffn2.w; d.b2 = ffn2.b;
-        d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.shortcut = shortcut;
-        if (next != nullptr) {
-            d.w1n = next->dc0.w; d.b1n = next->dc0.b; d.t1n = s.t1; d.ldt1 = next->cdc;
-        }
-        dcb_core(d, st);
         return;
     }
     {   // dc.3 (+ folded depthwise bias) + shortcut

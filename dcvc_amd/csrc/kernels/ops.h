@@ -36,10 +36,10 @@ struct GemmLaunchInfo {
     float ms;
 };
 size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap);
-// Other contraction kernels (dcb_core.hip) register their launches in the same list: when profiling
+// Other contraction kernels (dcb_nsplit.hip, dcb_tail.hip, ffn_fused.hip) register their launches in the same list: when profiling
 // is on, reserves a record and hands out the two events hipExtLaunchKernelGGL stamps; false = off.
 // info.K is chosen such that 2 * M * N * K is the launch's FLOP count; variant bits 28..31 name the kernel
-// family: 0 conv_gemm, 8 (bit 31) dcb_core, 2 dcb_tail, 3 ffn_fused, 4 dcb_nsplit.
+// family: 0 conv_gemm, 2 dcb_tail, 3 ffn_fused, 4 dcb_nsplit, 5 dcb_nsplit8 (8 was round 2's dcb_core).
 bool gemm_profile_slot(const GemmLaunchInfo& info, hipEvent_t* start, hipEvent_t* stop);
 // Tuning aid: when non-null, wave 0 of every workgroup of the following contraction launches
 // writes up to 16 shader-clock stamps (kernel entry, prologue issued, start of k-steps 0..7, main
@@ -61,31 +61,15 @@ struct Conv1x1Desc {
 };
 void conv1x1(const Conv1x1Desc& d, hipStream_t stream);
 
-// Full-width DepthConvBlock (C = 384) behind its depthwise conv in one launch (dcb_core.hip):
+// DepthConvBlock behind its depthwise conv in one launch, "N-split" form (dcb_nsplit.hip, round 3; round 2's register-resident
+// dcb_core kernel is in the history only):
 //   y1 = W3 t2 + b3 + x ; t = chunk_add(WSiLU(W0 y1 + b0)) ; y = (W2 t + b2 + y1 [+ x]) [* q] -> fp16 [* q2]
 //   and optionally the next block's dc.0: t1n = WSiLU(W1n y + b1n).
 // Bit-identical to conv1x1(dc.3) + conv1x1(ffn.0, wsilu, chunk_add) + conv1x1(ffn.2) [+ conv1x1(dc.0, wsilu)].
-struct DcbCoreDesc {
-    const half_t* t2 = nullptr; int ldt = 0;    // depthwise output [pixels][ldt]
-    const half_t* x = nullptr; int ldx = 0;     // block input (residual of dc.3; of ffn.2 too when shortcut)
-    const half_t* w3 = nullptr; const half_t* b3 = nullptr;     // dc.3 [c][c], folded bias
-    const half_t* w0 = nullptr; const half_t* b0 = nullptr;     // ffn.0 [4c][c]
-    const half_t* w2 = nullptr; const half_t* b2 = nullptr;     // ffn.2 [c][c]
-    const half_t* q = nullptr; const half_t* q2 = nullptr;      // scales fused / applied to the rounded output
-    const half_t* w1n = nullptr; const half_t* b1n = nullptr;   // next block's dc.0 (optional)
-    half_t* t1n = nullptr; int ldt1 = 0;                        // its output [pixels][ldt1]
-    half_t* y = nullptr; int ldy = 0;           // may alias x when !shortcut (a wave reads and writes only its own pixels)
-    int pixels = 0, c = 0;
-    bool shortcut = false;
-};
-bool dcb_core_supported(int c, int cdc, int cffn);
-void dcb_core_timeline_buffer(long long* device_buffer);     // tuning aid: [workgroups][64] shader-clock stamps
-void dcb_core(const DcbCoreDesc& d, hipStream_t stream);
-
-// The same block in "N-split" form (dcb_nsplit.hip, round 3): activations in LDS, every wave owns a quarter of
+// Activations in LDS, every wave owns a quarter of
 // the output channels and streams ITS weight fragments straight from L2 out of a pre-packed per-wave stream
 // (dcb_nsplit_pack_main / _dc0, packed once at set_param time). (c, ci) = (block width, inner width cdc = cffn):
-// (256, 256), (384, 384), (512, 512), (768, 768), and the half-width `dcb2` blocks (512, 256), (256, 128). Bit-identical to dcb_core and to
+// (256, 256), (384, 384), (512, 512), (768, 768), and the half-width `dcb2` blocks (512, 256), (256, 128). Bit-identical to
 // the launch sequence. y may alias x (a workgroup reads and writes only its own pixels).
 struct DcbNsplitDesc {
     const half_t* t2 = nullptr; int ldt = 0;

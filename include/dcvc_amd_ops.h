@@ -69,26 +69,20 @@ int dcvc_ffn_fused(const void* x, int ldx, const void* w0, const void* b0, const
                    const void* r2, int ldr2, const void* q, const void* q2, void* y, int ldy,
                    int pixels, int c, int cffn, void* stream);
 
-/* A full-width DepthConvBlock (c = 384: the intra encoder / decoder) behind its depthwise conv in ONE
- * launch (layers_proxy.cpp:81-98: conv1x1_bias_shortcut, conv1x1_bias_wsilu_chunk_add,
- * conv1x1_bias_shortcut[2][_with_quant]), optionally followed by dc.0 of the NEXT block of a chain
- * (conv1x1_bias_wsilu, layers_proxy.cpp:79):
+/* A DepthConvBlock behind its depthwise conv in ONE launch (layers_proxy.cpp:81-98: conv1x1_bias_shortcut,
+ * conv1x1_bias_wsilu_chunk_add, conv1x1_bias_shortcut[2][_with_quant]), optionally followed by dc.0 of the NEXT block of a
+ * chain (conv1x1_bias_wsilu, layers_proxy.cpp:79):
  *   y1 = W3 * t2 + b3 + x;  y = (W2 * chunk_add(WSiLU(W0 * y1 + b0)) + b2 + y1 [+ x]) [* q] -> fp16 [* q2];
  *   t1n = WSiLU(W1n * y + b1n)   (when w1n != NULL).
- * t2 = depthwise output [pixels][ldt], x = block input [pixels][ldx], b3 = dc.3 bias with the
- * depthwise bias folded in. Bit-identical to the separate launches; y may alias x when !shortcut. */
-int dcvc_dcb_core(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
-                  const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
-                  const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
-                  int pixels, int c, int shortcut, void* stream);
-
-/* The same operator (plus the inner width ci = cdc = cffn) through the N-split kernel (round 3: activations in LDS, every wave owns a quarter
+ * t2 = depthwise output [pixels][ldt], x = block input [pixels][ldx], b3 = dc.3 bias with the depthwise bias folded in,
+ * ci = inner width (cdc = cffn). Bit-identical to the separate launches; y may alias x when !shortcut.
+ * The N-split kernel (round 3: activations in LDS, every wave owns a share
  * of the output channels and streams its weight fragments from a packed copy of w3 | w0 | w2 [| w1n] that this entry point
  * builds on EVERY call in stream-ordered temporaries - the codecs pack once at set_param time; callers that launch many
  * times use the handle form below).
  * (c, ci) in {(256, 256), (384, 384), (512, 512), (768, 768)} - full-width blocks - and {(512, 256), (256, 128)}: the
  * half-width `dcb2` blocks of the inter models (layers.py:128-159; w3 [c][ci], w0 [4 ci][c], w2 [c][ci], w1n [ci][c]).
- * Bit-identical to dcvc_dcb_core / dcvc_dcb_tail and to the separate launches. */
+ * Bit-identical to dcvc_dcb_tail and to the separate launches. */
 int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
                     const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
                     const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
@@ -141,8 +135,6 @@ int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H, int W, void* y16,
 /* Tuning aid (no reference counterpart): device buffer of [blocks][16] int64 shader-clock stamps
  * written by wave 0 of every workgroup of the following contraction launches; NULL = off. */
 int dcvc_gemm_timeline_buffer(void* device_buffer);
-/* the same for dcvc_dcb_core: [workgroups][64] stamps (entry, then one per weight slab) */
-int dcvc_dcb_core_timeline_buffer(void* device_buffer);
 int dcvc_dcb_nsplit_timeline_buffer(void* device_buffer);   /* [workgroups][32] stamps of the N-split block kernel */
 
 /* def_elementwise.h: round_z_cuda / int8_to_dtype_cuda */

@@ -42,8 +42,6 @@ class Ops:
         self.ffn_fused = _f("dcvc_ffn_fused", [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp])
         self.dcb_tail = _f("dcvc_dcb_tail", [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci,
                                              ci, ci, ci, ci, ci, ci, vp])
-        self.dcb_core = _f("dcvc_dcb_core", [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci,
-                                             ci, ci, ci, vp])
         self.dcb_nsplit = _f("dcvc_dcb_nsplit", [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci,
                                                  ci, ci, ci, ci, vp])
         self.dcb_nsplit_pack = _f("dcvc_dcb_nsplit_pack", [vp, vp, vp, vp, ci, ci, vp, ctypes.POINTER(vp)])

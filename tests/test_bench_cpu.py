@@ -178,7 +178,7 @@ def fake_gpu(monkeypatch):
     monkeypatch.setattr(bench, "make_pictures", lambda n, rank, device, height=1080, width=1920: [_FakePicture(height, width)] * n)
     monkeypatch.setattr(bench, "IntraWorkload", _FakeWork)
     monkeypatch.setattr(bench, "InterWorkload", _FakeInter)
-    monkeypatch.setattr(bench, "roofline", lambda work, n=5: {"bound": "mfma", "kernel": "dcb_core_kernel", "achieved": 1.0,
+    monkeypatch.setattr(bench, "roofline", lambda work, n=5: {"bound": "mfma", "kernel": "dcb_nsplit8_kernel<384, 384, 64 px>", "achieved": 1.0,
                                                              "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.0004, "traffic": None,
                                                              "all_contractions": {"achieved": 0.9, "frac": 0.00036}})
     monkeypatch.setattr(bench, "cpu_baseline", lambda net, device: {"value": 1e-3, "unit": "frames/s", "cores": 1,
@@ -212,7 +212,7 @@ def test_one_json_line_with_the_contract_fields(fake_gpu, monkeypatch, capsys):
     # the K timed steps stay exactly K; the longer region behind them is reported beside, never instead
     assert d["sustained"]["seconds"] >= 0.25 and d["sustained"]["steps"] >= 7 and d["sustained"]["value"] > 0
     assert d["uhd"]["resolution"] == "3840x2160" and set(d["uhd"]) == {"resolution", "intra", "ld", "hts", "htl", "sweep64"}
-    assert d["roofline"]["kernel"] == "dcb_core_kernel" and "all_contractions" in d["roofline"]
+    assert d["roofline"]["kernel"].startswith("dcb_nsplit8_kernel") and "all_contractions" in d["roofline"]
     assert all("roofline" in o for o in d["other_workloads"].values())
     assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f16"

@@ -202,8 +202,7 @@ def test_inter_matches_oracle_digest(name):
                          "ld_1280x720 or hts_1280x720 or htl_1280x720", 7),
     # round 3's 4-wave block kernel (dcb_nsplit) instead of round 4's 8-wave one (dcb_nsplit8): its own weight stream layout
     ("DCVC_NSPLIT_WAVES", "dmci_1280x720_q32_t0.15 or ld_1280x720 or hts_1280x720 or htl_1280x720", 4),
-    # no N-split kernel at all: dcb_tail / ffn_fused for the half-width blocks, the launch sequence (or, in a
-    # -DDCVC_WITH_DCB_CORE build, round 2's dcb_core) for the full-width ones
+    # no N-split kernel at all: dcb_tail / ffn_fused for the half-width blocks, the launch sequence for the full-width ones
     ("DCVC_NSPLIT", "dmci_256x256 or ld_1280x720", 2),
 ])
 def test_other_kernel_paths_match_the_digests(switch, pick, count):

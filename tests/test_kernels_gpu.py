@@ -523,84 +523,6 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
 
 
-def _has_dcb_core(ops):
-    """the default build carries a stand-in for round 2's dcb_core (kernels/dcb_core_off.hip): its entry point reports so"""
-    from dcvc_amd import _lib
-    from gpu_util import stream
-    rc = ops.dcb_core(None, 0, None, 0, None, None, None, None, None, None, None, None, None, None, None, 0, None, 0, 1, 384, 0, stream())
-    if rc >= 0:
-        return True
-    return "not part of this build" not in _lib.lib().dcvc_last_error().decode("utf-8", "replace")
-
-
-@pytest.mark.parametrize("P,shortcut,quant,q2,nxt,inplace", [
-    (128, False, False, False, False, False),       # one workgroup
-    (300, False, False, False, True, True),         # ragged last workgroup, in place, next dc.0 fused
-    (1000, True, False, False, False, False),       # block shortcut (not in place)
-    (777, False, True, False, True, True),          # fused quant (the inter encoders' conv2 form)
-    (2040, False, False, True, True, False),        # scale on the rounded output + next dc.0
-    (32640, False, False, False, True, True),       # 1080p P8 grid (255 workgroups), the chain configuration
-    (32640, True, False, True, False, False),
-])
-def test_dcb_core_equals_launch_sequence(ops, P, shortcut, quant, q2, nxt, inplace):
-    """dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) of a full-width DepthConvBlock in ONE launch
-    (dcb_core.hip) == conv1x1(dc.3, residual) -> conv1x1(ffn.0, wsilu, chunk_add) -> conv1x1(ffn.2,
-    residuals, quant) (-> conv1x1(dc.0, wsilu)), bit for bit; those launches are checked against
-    the oracle above."""
-    from gpu_util import call, ptr, stream
-    if not _has_dcb_core(ops):
-        pytest.skip("dcb_core (round 2's block kernel) is built on request only: DCVC_EXTRA_DEFS=-DDCVC_WITH_DCB_CORE")
-    dev, C = "cuda", 384
-    ldx = C + 64
-    xbuf = _rand((P, ldx), 1.0, 301).to(dev)
-    t2 = _rand((P, C), 1.0, 302).to(dev)
-    w3 = (_rand((C, C), 1.0, 303) / C ** 0.5).half().to(dev)
-    b3 = _rand((C,), 0.3, 304).to(dev)
-    w0 = (_rand((4 * C, C), 1.0, 305) / C ** 0.5).half().to(dev)
-    b0 = _rand((4 * C,), 0.3, 306).to(dev)
-    w2 = (_rand((C, C), 1.0, 307) / C ** 0.5).half().to(dev)
-    b2 = _rand((C,), 0.3, 308).to(dev)
-    w1 = (_rand((C, C), 1.0, 309) / C ** 0.5).half().to(dev)
-    b1 = _rand((C,), 0.3, 310).to(dev)
-    q = (_rand((C,), 0.2, 311) + 1.0).half().to(dev) if quant else None
-    qq = (_rand((C,), 0.2, 312) + 1.0).half().to(dev) if q2 else None
-    # the launch sequence
-    y1 = torch.zeros((P, C), dtype=torch.half, device=dev)
-    t = torch.zeros((P, C), dtype=torch.half, device=dev)
-    want = torch.zeros((P, C), dtype=torch.half, device=dev)
-    want_t1 = torch.zeros((P, C), dtype=torch.half, device=dev)
-    call(ops.conv1x1, ptr(t2), C, ptr(w3), ptr(b3), ptr(xbuf), ldx, None, 0, None, None, ptr(y1), C, P, C, C, 0, stream())
-    call(ops.conv1x1, ptr(y1), C, ptr(w0), ptr(b0), None, 0, None, 0, None, None, ptr(t), C, P, C, 4 * C, 3, stream())
-    call(ops.conv1x1, ptr(t), C, ptr(w2), ptr(b2), ptr(y1), C, ptr(xbuf) if shortcut else None, ldx, ptr(q), ptr(qq),
-         ptr(want), C, P, C, C, 0, stream())
-    call(ops.conv1x1, ptr(want), C, ptr(w1), ptr(b1), None, 0, None, 0, None, None, ptr(want_t1), C, P, C, C, 1, stream())
-    torch.cuda.synchronize()
-    # one launch
-    if inplace:
-        ybuf, ldy = xbuf.clone(), ldx
-        xin = ybuf
-    else:
-        ybuf, ldy = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev), C + 8
-        xin = xbuf
-    t1 = torch.full((P, C + 8), 7.0, dtype=torch.half, device=dev)
-    call(ops.dcb_core, ptr(t2), C, ptr(xin), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), ptr(qq),
-         ptr(w1) if nxt else None, ptr(b1) if nxt else None, ptr(t1) if nxt else None, C + 8, ptr(ybuf), ldy,
-         P, C, 1 if shortcut else 0, stream())
-    torch.cuda.synchronize()
-    bad = int((ybuf[:, :C] != want).sum())
-    assert bad == 0, "y: %d of %d outputs differ" % (bad, want.numel())
-    if inplace:
-        assert torch.equal(ybuf[:, C:], xbuf[:, C:]), "channels beyond C untouched"
-    else:
-        assert (ybuf[:, C:] == 9.0).all()
-    if nxt:
-        bad = int((t1[:, :C] != want_t1).sum())
-        assert bad == 0, "next dc.0: %d of %d outputs differ" % (bad, want_t1.numel())
-        assert (t1[:, C:] == 7.0).all()
-    else:
-        assert (t1 == 7.0).all()
-
-
 @pytest.mark.parametrize("C,CI,P,shortcut,quant,q2,nxt,inplace", [
     (384, 384, 64, False, False, False, False, False),   # one 64-pixel workgroup
     (384, 384, 100, False, False, False, True, True),    # 32-pixel workgroups, ragged last one, in place, next dc.0
@@ -640,8 +562,7 @@ def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, n
     """The same block through kernels/dcb_nsplit.hip (round 3: activations in LDS, every wave streams its quarter of
     every weight matrix from a packed copy) == the launch sequence conv1x1(dc.3, residual) -> conv1x1(ffn.0, wsilu,
     chunk_add) -> conv1x1(ffn.2, residuals, quant) (-> conv1x1(dc.0, wsilu)), bit for bit, for full- and half-width
-    blocks (CI = inner width), both workgroup sizes, ragged grids, in place and out of place; where dcb_core exists
-    (C = 384) it agrees too."""
+    blocks (CI = inner width), both workgroup sizes, ragged grids, in place and out of place."""
     from gpu_util import call, ptr, stream
     dev = "cuda"
     ldx = C + 64
@@ -695,9 +616,6 @@ def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, n
         assert (t1[:, CI:] == 7.0).all()
     else:
         assert (t1 == 7.0).all()
-    if C == 384 and _has_dcb_core(ops):
-        y2, t12 = run(ops.dcb_core)
-        assert torch.equal(y2, ybuf) and torch.equal(t12, t1)
 
 
 def test_dcb_nsplit_reads_the_weights_of_the_call(ops):
