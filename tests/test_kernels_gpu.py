@@ -173,16 +173,17 @@ def test_dwconv3x3(ops, H, W, C):
     assert torch.equal(ys[:, :, 16:16 + C], y) and float(ys[:, :, :16].abs().max()) == 0 and float(ys[:, :, 16 + C:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("mode", ["sliding", "ahead"])
-def test_dwconv3x3_other_modes(mode):
-    """the round-1 sliding-window kernel and the default-register-budget form of the load-ahead kernel (DCVC_DWCONV_MODE,
-    read once per process): same arithmetic, same bits; prints the launch time of all three forms at 1080p / 8"""
+@pytest.mark.parametrize("variant", ["8,1", "8,2", "4,2", "16,1", "8,3"])
+def test_dwconv3x3_other_variants(variant):
+    """the other instantiations of the depthwise walk (rows per lane, rows of loads in flight; DCVC_DWCONV_VARIANT, read once
+    per process): same arithmetic, same bits; prints the launch time of each at 1080p / 8"""
     import subprocess
     import sys
-    env = dict(os.environ, DCVC_DWCONV_MODE=mode)
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
-                          "test_dwconv3x3 and not other_modes", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0 and "10 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]
+    env = dict(os.environ, DCVC_DWCONV_VARIANT=variant)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-s", "-k",
+                          "test_dwconv3x3 and not other_variants", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    print("\n".join(l for l in res.stdout.splitlines() if "us per launch" in l))
+    assert res.returncode == 0 and "11 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]
 
 
 def test_dwconv3x3_launch_time(ops):
@@ -204,7 +205,7 @@ def test_dwconv3x3_launch_time(ops):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 200
     print("dwconv3x3 %s: %.2f us per launch, %.2f TB/s of the 50.1 MB a launch has to move" % (
-        os.environ.get("DCVC_DWCONV_MODE", "deep (default)"), us, 2 * H * W * C * 2 / us / 1e6))
+        os.environ.get("DCVC_DWCONV_VARIANT", "default (8,2; 4,2 for <= 128 channels)"), us, 2 * H * W * C * 2 / us / 1e6))
 
 
 def test_layout_kernels_exact(ops):
