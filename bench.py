@@ -179,8 +179,11 @@ class IntraWorkload:
         self.sps = {"height": self.height, "width": self.width}
         self.overlapped = dec_net is not None and prioritised
         if self.overlapped and os.environ.get("DCVC_BENCH_PRIORITIES", "1") != "0":
-            os.environ["DCVC_COMPUTE_PRIORITY"] = "high"
-            self.dec._ensure_proxy()
+            # (the priority of a codec's streams is read when the native object is created: `gpu_net` must be an object that
+            # has not coded anything yet - make_work() passes a fresh one)
+            for obj, prio in ((self.net, "low"), (self.dec, "high")):
+                os.environ["DCVC_COMPUTE_PRIORITY"] = prio
+                obj._ensure_proxy()
             del os.environ["DCVC_COMPUTE_PRIORITY"]
 
     def prepare(self, i):
@@ -1118,7 +1121,9 @@ def main():
         pics = make_pictures(frames, rank, device, h, w)
         pad_r, pad_b = gpu_net.get_padding_size(h, w, 16)
         if kind == "intra":
-            return IntraWorkload(gpu_net, pics, pad_b, pad_r, _to_gpu(cpu_net, device) if prioritised else None, prioritised)
+            if prioritised:      # encoder and decoder objects of their own (low / high priority streams)
+                return IntraWorkload(_to_gpu(cpu_net, device), pics, pad_b, pad_r, _to_gpu(cpu_net, device), True)
+            return IntraWorkload(gpu_net, pics, pad_b, pad_r)
         return InterWorkload(kind, device, pics, gpu_net, pad_b, pad_r, prioritised)
 
     def sync():

@@ -12,15 +12,21 @@ CodecBase::CodecBase()
 {
     int lo = 0, hi = 0;
     hip_check(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
-    hip_check(hipStreamCreateWithPriority(&m_io_stream, hipStreamNonBlocking, hi), "hipStreamCreate(io)");
-    // DCVC_COMPUTE_PRIORITY = high | low, read when a codec object is created: the priority of its compute stream. A
+    // DCVC_COMPUTE_PRIORITY = high | low, read when a codec object is created: the priority of its streams. A
     // decoder that shares a GPU with an encoder (bench.py's two-stage loop) is a chain of short kernels and host round
-    // trips - at equal priority every one of them queues behind a kernel of the encoder's burst
-    int prio = 0;
+    // trips - at equal priority every one of them queues behind a kernel of the encoder's burst.
+    // The transfer stream follows: HIP multiplexes the streams of one priority level onto a few hardware queues, and the
+    // transfer stream carries "wait for this object's stage" barriers - an ENCODER's transfer stream at high priority could
+    // land on the hardware queue of the DECODER's compute stream and park the decoder's kernels behind the encoder's stage
+    // (round 5, profiles/r05_pipeline_order.txt: the same two-stage loop reached 109 or 178 pictures/s depending only on which
+    // objects had been created before). An object created without the variable keeps its transfers at high priority.
+    int prio = 0, io_prio = hi;
     if (const char* e = getenv("DCVC_COMPUTE_PRIORITY")) {
         const std::string v(e);
         prio = v == "high" ? hi : v == "low" ? lo : 0;
+        io_prio = v == "low" ? lo : hi;
     }
+    hip_check(hipStreamCreateWithPriority(&m_io_stream, hipStreamNonBlocking, io_prio), "hipStreamCreate(io)");
     hip_check(hipStreamCreateWithPriority(&m_cs, hipStreamNonBlocking, prio), "hipStreamCreate(compute)");
     hip_check(hipEventCreateWithFlags(&m_ev_job, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&m_ev_in, hipEventDisableTiming), "hipEventCreate");
