@@ -45,6 +45,24 @@ def main():
     elif order == "fresh-encoder":
         # the plain loop on gpu_net as before, the pipeline with an encoder object that never decoded
         print(order, "plain %.1f" % plain(40), "then pipelined with a fresh encoder object %.1f (sustained %.1f)" % pipe(bench._to_gpu(cpu_net, device)))
+    elif order == "seq-two":
+        # ONE thread, compress then decompress, but on two objects (encoder streams low, decoder streams high): the
+        # decoder's chain of short kernels and host round trips can run under the encoder's reconstruction tail
+        a = plain(40)
+        w = bench.IntraWorkload(bench._to_gpu(cpu_net, device), pics, pad_b, pad_r, bench._to_gpu(cpu_net, device), True)
+        bench.run_steps(w, 0, 10)
+        dt, _ = bench.timed_region(w, bench.run_steps, 10, 60)
+        ok = bench.closure_ok(w, 70)
+        print(order, "plain (one object) %.1f then two prioritised objects, same sequential loop %.1f closure %s" % (a, 60 / dt, ok))
+    elif order == "seq-two-ld":
+        w = bench.InterWorkload("ld", device, pics, gpu_net, pad_b, pad_r, False)
+        bench.run_steps(w, 0, 12)
+        dt, _ = bench.timed_region(w, bench.run_steps, 12, 96)
+        a = 96 / dt
+        w2 = bench.InterWorkload("ld", device, pics, gpu_net, pad_b, pad_r, True)
+        bench.run_steps(w2, 0, 12)
+        dt, _ = bench.timed_region(w2, bench.run_steps, 12, 96)
+        print(order, "LD sequential loop, plain objects %.1f, prioritised objects %.1f" % (a, 96 / dt))
     elif order == "idle-between":
         a = plain(400)
         time.sleep(3.0)
