@@ -179,7 +179,9 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     p.timeline = g_ns_timeline;
     // 64-pixel workgroups when they fill the chip (picture resolution / 8), 32 otherwise (/ 16: 255 workgroups at 1080p)
     // (768-wide blocks - the hierarchical models' prior fusion at / 16 - have LDS for 32 pixels only)
-    const bool wide = d.pixels >= 64 * 200 && d.c < 768;
+    // DCVC_NSPLIT_PX=32: 32-pixel workgroups everywhere (A/B: twice the tiles per workgroup, half the work per weight byte)
+    static const bool narrow_all = [] { const char* e = getenv("DCVC_NSPLIT_PX"); return e != nullptr && atoi(e) == 32; }();
+    const bool wide = d.pixels >= 64 * 200 && d.c < 768 && !narrow_all;
     const bool next = d.wnext != nullptr;
     if (dcb_nsplit_waves() == 8) {
         if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
