@@ -619,7 +619,7 @@ def cpu_baseline(cpu_net, device):
     }
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
 KERNEL_SOURCES = ("dcb_nsplit8_kernel.h", "dcb_nsplit_kernel.h", "dcb_nsplit.hip", "conv_gemm.hip", "dcb_tail.hip", "ffn_fused.hip", "dwconv.hip",
                   "arith.h")
 

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-FAMILIES = ("dcb_core_kernel", "conv_gemm_kernel", "dwconv3x3_kernel", "dcb_tail_kernel", "ffn_fused_kernel")
+FAMILIES = ("conv_gemm_kernel", "dwconv3x3", "dcb_tail_kernel", "ffn_fused_kernel")
 NSPLIT = re.compile(r"dcb_nsplit(8?)_kernel<(\d+), (\d+), (\d+), (true|false)>")
 NSPLIT_MANGLED = re.compile(r"dcb_nsplit(8?)_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E")
 
@@ -25,7 +25,7 @@ def family(name):
         return "dcb_nsplit%s_kernel<%s, %s, %d px>" % (m.group(1), m.group(2), m.group(3), 32 * int(m.group(4)))
     for f in FAMILIES:
         if f in name:
-            return f
+            return "dwconv3x3_kernel" if f == "dwconv3x3" else f        # (every instantiation of the depthwise walk)
     return None
 
 
