@@ -58,6 +58,15 @@ import os
 import sys
 import time
 
+# ONE hardware queue per stream-priority level (ROCclr's GPU_MAX_HW_QUEUES, default 4), set before the HIP runtime starts:
+# every codec object brings two streams, HIP deals the streams of a priority level out over up to 4 hardware queues, and with
+# the default what a loop reaches depended on which objects had been created in the process before - LD's sequential loop 182
+# or 325 pictures/s, HT-S's 479 / 544 / 733, the intra pipeline 101 / 109 / 155 / 180 in the round-5 sessions, each value
+# reproducible for its creation order. With one queue per level every order gave the best of those
+# (profiles/r05_hw_queues.txt). INTEGRATION.md recommends the setting to every host of the plug-in; an explicit value in the
+# environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+
 import numpy as np
 import torch
 
@@ -748,7 +757,8 @@ def common_fields(env, fps, elapsed, steps, scaling, metric, config):
             "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the reference architecture)",
-            "config": config, "box": box_identity(env.device)}
+            "config": config, "box": box_identity(env.device),
+            "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
 
 
 def run_default(env, make_work):
@@ -832,9 +842,10 @@ def run_default(env, make_work):
         "fps_method": "value: K steps of the sequential loop between device synchronisations; encode_fps / decode_fps: the "
                       "reference's loop (events around each call on a synchronised device, first %d calls dropped, rank 0), "
                       "measured behind every throughput loop of the process (see `measurement_order`)" % DROP_CALLS,
-        "measurement_order": "phase A: every loop whose result is a throughput (value, sustained, pipelined, other_workloads, uhd, "
-                             "sweep64) before any timing event exists in the process; phase B: the per-call event loops "
-                             "(encode_fps / decode_fps) and the event-stamped roofline passes, on the same objects",
+        "measurement_order": "phase A1: the plain loops of every workload (value, sustained, other_workloads, uhd, sweep64); phase A2: "
+                             "the two-stage pipelines on objects of their own (priority streams); phase B: the per-call event loops "
+                             "(encode_fps / decode_fps) and the event-stamped roofline passes on the objects of A1 - no timing event "
+                             "and no priority stream exists in the process while a plain loop is measured",
         "loop": loop_text,
         "bytes_per_picture": nbytes / args.steps / work.frames,
         "bpp": 8.0 * nbytes / args.steps / work.frames / (height * width),
@@ -843,22 +854,20 @@ def run_default(env, make_work):
     if sustained is not None:
         out["sustained"] = sustained
     extras = world == 1 and not args.no_extras
-    # ---------------------------------------------------------------- phase A, continued: loops only
-    if world == 1 and not args.no_pipeline:
-        wp = make_work(args.workload, height, width, prioritised=True)
-        out["pipelined"] = pipelined_block(wp, 0, args.steps, args.warmup, args.min_seconds)
-        del wp
-        torch.cuda.empty_cache()
-    kept = []          # (report, plain objects, next step index, with_roofline) of phase A, for phase B
+    # ---------------------------------------------------------------- phase A1, continued: the plain loops of every workload
+    kept = []          # (report, plain objects, next step index) of phase A1, for phase B
+    pipelines = []     # (report, factory, steps, warmup) of the two-stage pipelines, measured in phase A2
     if extras:
         others = {}
         for kind in NAMES:
             if kind == args.workload:
                 continue
-            o, w, nxt = fps_block_a(lambda pr, kind=kind: make_work(kind, height, width, prioritised=pr),
-                                    48 if kind in ("hts", "htl") else 96, 12, with_pipeline=not args.no_pipeline)
+            steps = 48 if kind in ("hts", "htl") else 96
+            make = (lambda pr, kind=kind: make_work(kind, height, width, prioritised=pr))
+            o, w, nxt = fps_block_a(make, steps, 12, with_pipeline=False)
             others[kind] = o
             kept.append((o, w, nxt))
+            pipelines.append((o, make, steps, 12))
         out["other_workloads"] = others
         if not args.no_uhd and (height, width) == (HEIGHT, WIDTH):
             uhd = {"resolution": "3840x2160"}
@@ -870,6 +879,21 @@ def run_default(env, make_work):
             # BASELINE configs[4]: the 64-point rate sweep at 3840x2160, as a short run (1 I + 2 P pictures per rate point)
             uhd["sweep64"] = sweep64_block(env, "ld", 2160, 3840, 2)
             out["uhd"] = uhd
+    # ---------------------------------------------------------------- phase A2: the two-stage pipelines (objects of their own,
+    # streams at low / high priority) - behind every plain loop: what a plain loop on separate encoder / decoder objects reaches
+    # depends on which streams have been created in the process before (profiles/r05_pipeline_order.txt: HIP multiplexes the
+    # streams of a priority level onto a few hardware queues), and streams of a NEW priority level in front of the plain LD /
+    # HT-S loops halved them in one session (r05 closing session, first attempt: LD 182 instead of 325 pictures/s)
+    if world == 1 and not args.no_pipeline:
+        wp = make_work(args.workload, height, width, prioritised=True)
+        out["pipelined"] = pipelined_block(wp, 0, args.steps, args.warmup, args.min_seconds)
+        del wp
+        torch.cuda.empty_cache()
+        for o, make, steps, warm in pipelines:
+            wp = make(True)
+            o["pipelined"] = pipelined_block(wp, 0, steps, warm)
+            del wp
+            torch.cuda.empty_cache()
     # ---------------------------------------------------------------- phase B: the event-stamped passes
     if not fanout:
         te, td = call_times(work, cursor, ncalls)

@@ -485,6 +485,10 @@ int decode(const Args& a)
 
 int main(int argc, char** argv)
 {
+    // one hardware queue per stream-priority level, before the HIP runtime starts ("Runtime settings":
+    // with ROCclr's default of 4 the throughput of several codec objects in one process depends on their creation order);
+    // a value in the environment wins
+    setenv("GPU_MAX_HW_QUEUES", "1", 0);
     if (argc < 2) die("usage: dcvc encode|decode ... (see the head of dcvc_cli.hip)");
     const std::string mode = argv[1];
     try {

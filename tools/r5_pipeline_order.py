@@ -9,6 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")      # this probe is about the runtime's DEFAULT; bench.py itself sets 1
 import bench  # noqa: E402
 
 
