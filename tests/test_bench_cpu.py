@@ -438,6 +438,27 @@ def test_gop_hand_off_mode_over_two_ranks():
 
 
 @pytest.mark.timeout(300)
+def test_rate_sweep_sharded_over_two_ranks():
+    """`bench.py --gpus 2 --sweep64`: the 64 rate points are split over the ranks (sharding.shard_range), every rank reports
+    its points with its closure flags (all_gather_object over gloo here), rank 0 prints the one line with all 64 in order."""
+    env = dict(os.environ, DCVC_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_launch_child.py")
+    res = subprocess.run([sys.executable, child, "--gpus", "2", "--sweep64", "--workload", "ld", "--sweep-units", "2"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    sw = d["sweep64"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 64 and d["config"]["resolution"] == "3840x2160"
+    assert sw["rate_points"] == 64 and len(sw["closure_ok_per_q"]) == 64 and all(sw["closure_ok_per_q"]) and d["closure_ok"] is True
+    assert sw["pictures_per_rate_point"] == 3 and sw["bpp_per_q"] == sorted(sw["bpp_per_q"])
+    assert res.stderr.count("done in") == 2
+
+
+@pytest.mark.timeout(300)
 def test_gpus_flag_spawns_the_ranks_itself():
     """`python bench.py --gpus 2` with NO launcher around it (how the driver calls it): the process re-launches
     itself under torch.distributed.run, both ranks rendezvous on 127.0.0.1, run the real main() - barriers, shard of
