@@ -509,22 +509,26 @@ static void conv1x1_epilogue(const float* v, int p, const uint16_t* r1, int ldr1
     }
 }
 
-/* Threads for a loop of `work` independent items in chunks of `grain`: never more than there are chunks, and never
- * more than ORACLE_THREADS (environment; default 32). The GPU box's host has 256 hardware threads on two sockets: a team
- * of 256 woken for the 64 pixels of a 64x64 test picture, thousands of times per picture, made the small live-oracle
- * tests 5x slower there than on the 8-core build container (measured in round 5). */
+/* ONE team size for every parallel region of the oracle: min(OpenMP's maximum, ORACLE_THREADS (environment; default 16)).
+ * Round 5, measured: (i) the GPU box's host has 256 hardware threads on two sockets - a team of 256 woken for the 64
+ * pixels of a 64x64 test picture, thousands of times per picture, made the small live-oracle tests 5x slower there than on
+ * the 8-core build container; (ii) sizing the team by the work of each loop was worse still: libgomp re-forms its team
+ * whenever consecutive regions ask for different sizes, ~ 25 ms each time on the build container (a 2048 x 512 layer on
+ * ONE pixel took 58 ms with an 8-thread weight split in front of a 1-thread pixel loop, 11 ms with one size for both).
+ * `work` / `grain` are kept in the signature for the call sites' documentation value only. */
 static int orc_threads(int64_t work, int grain)
 {
 #ifdef _OPENMP
     static int cap = 0;
-    int64_t n = (work + grain - 1) / grain;
+    (void)work;
+    (void)grain;
     if (cap == 0) {
         const char* e = getenv("ORACLE_THREADS");
-        int c = e ? atoi(e) : 32;
+        int c = e ? atoi(e) : 16;
         int m = omp_get_max_threads();
         cap = c < 1 ? 1 : (c > m ? m : c);
     }
-    return (int)(n < 1 ? 1 : (n > cap ? cap : n));
+    return cap;
 #else
     (void)work;
     (void)grain;
@@ -547,34 +551,59 @@ void orc_conv1x1(const uint16_t* x, int ldx, const uint16_t* w, const uint16_t* 
         /* k-major planes: wm[k][n], we[k][n] */
         int32_t* wm = (int32_t*)malloc(sizeof(int32_t) * (size_t)N * K * 2);
         int32_t* we = wm + (size_t)N * K;
-        int n, k;
+        int n;
+        /* (the transposing split of the weight matrix is the fixed cost of a call - 10.6 of the 13.3 ms of a 2048 x 512 layer
+         * on a 64-pixel test picture when it ran on one thread: rows in parallel) */
+#pragma omp parallel for schedule(static) num_threads(orc_threads(N, 256))
         for (n = 0; n < N; n++) {
+            int k;
             for (k = 0; k < K; k++) {
                 split_planes(w[(size_t)n * K + k], &wm[(size_t)k * N + n], &we[(size_t)k * N + n]);
             }
         }
-#pragma omp parallel for schedule(dynamic, 8) num_threads(orc_threads(P, 8))
-        for (p = 0; p < P; p++) {
-            int32_t* xm = (int32_t*)malloc(sizeof(int32_t) * (size_t)K * 2);
-            int32_t* xe = xm + K;
-            float* v = (float*)malloc(sizeof(float) * (size_t)N);
-            for (k = 0; k < K; k++) {
-                split_planes(x[(size_t)p * ldx + k], &xm[k], &xe[k]);
-            }
-            for (n = 0; n < N; n++) {
-                v[n] = bias ? half_to_float(bias[n]) : 0.0f;
-            }
-            for (n = 0; n < N; n += 16) {
-                dot16_avx512(v + n, wm + n, we + n, N, xm, xe, K);
-            }
-            if ((flags & ORC_WSILU) && !(flags & ORC_CHUNK_ADD)) {
-                for (n = 0; n < N; n++) {
-                    v[n] = wsilu_spec(v[n]);
+        /* Pixels in blocks of ORC_PB: the 16-column weight slab of a column group (K x 16 x two planes = 64 KB at K = 512)
+         * is walked once per BLOCK and stays in the core's L2 for the block's pixels. Round 5: with one pixel per pass
+         * every pixel streamed the layer's whole split weight matrix (8 MB for ffn.0 of a 512-wide block) from memory -
+         * 8 threads on a 64-pixel test picture ran SLOWER than one (104 against 63 ms per call on the build container).
+         * Every (pixel, column group) is still one dot16_avx512 call with the same operands: bit-identical. */
+        {
+        enum { ORC_PB = 8 };
+        const int nblocks = (P + ORC_PB - 1) / ORC_PB;
+        int pb;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_threads(nblocks, 1))
+        for (pb = 0; pb < nblocks; pb++) {
+            const int p0 = pb * ORC_PB;
+            const int np = (P - p0 < ORC_PB) ? P - p0 : ORC_PB;
+            int32_t* xm = (int32_t*)malloc(sizeof(int32_t) * (size_t)K * 2 * ORC_PB);
+            float* v = (float*)malloc(sizeof(float) * (size_t)N * ORC_PB);
+            int pi, kk, nn;
+            for (pi = 0; pi < np; pi++) {
+                int32_t* xmp = xm + (size_t)pi * 2 * K;
+                for (kk = 0; kk < K; kk++) {
+                    split_planes(x[(size_t)(p0 + pi) * ldx + kk], &xmp[kk], &xmp[K + kk]);
+                }
+                for (nn = 0; nn < N; nn++) {
+                    v[(size_t)pi * N + nn] = bias ? half_to_float(bias[nn]) : 0.0f;
                 }
             }
-            conv1x1_epilogue(v, p, r1, ldr1, r2, ldr2, q, q2, y, ldy, N, flags);
+            for (nn = 0; nn < N; nn += 16) {
+                for (pi = 0; pi < np; pi++) {
+                    const int32_t* xmp = xm + (size_t)pi * 2 * K;
+                    dot16_avx512(v + (size_t)pi * N + nn, wm + nn, we + nn, N, xmp, xmp + K, K);
+                }
+            }
+            for (pi = 0; pi < np; pi++) {
+                float* vp = v + (size_t)pi * N;
+                if ((flags & ORC_WSILU) && !(flags & ORC_CHUNK_ADD)) {
+                    for (nn = 0; nn < N; nn++) {
+                        vp[nn] = wsilu_spec(vp[nn]);
+                    }
+                }
+                conv1x1_epilogue(vp, p0 + pi, r1, ldr1, r2, ldr2, q, q2, y, ldy, N, flags);
+            }
             free(xm);
             free(v);
+        }
         }
         free(wm);
         return;
