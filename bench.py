@@ -64,8 +64,12 @@ import time
 # or 325 pictures/s, HT-S's 479 / 544 / 733, the intra pipeline 101 / 109 / 155 / 180 in the round-5 sessions, each value
 # reproducible for its creation order. With one queue per level every order gave the best of those
 # (profiles/r05_hw_queues.txt). INTEGRATION.md recommends the setting to every host of the plug-in; an explicit value in the
-# environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+# environment wins. ONLY for a one-rank run: with RCCL in the process (--gpus N, --fanout, --handoff) its kernels would share the
+# normal-priority hardware queue with the codecs' compute streams and the fan-out's broadcast / the hand-off's sends would lose
+# the overlap they are timed on - never measured, so the N-rank children keep the runtime's default (advisor, round 5). Decided
+# here, in front of the HIP runtime's start-up, from what the launcher exported; the setting in force is in the line's `runtime_env`.
+if int(os.environ.get("WORLD_SIZE", "1") or "1") <= 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 
 import numpy as np
 import torch
@@ -913,7 +917,44 @@ def run_default(env, make_work):
         torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline and args.workload == "intra":
         out["cpu_baseline"] = cpu_baseline(env.cpu_net, device)
+    other = compact_other(out)
+    if other:
+        out["config"]["other"] = other
+        out["config"]["other_fields"] = "[pictures/s of the sequential loop, encode_fps, decode_fps] per workload"
     return out
+
+
+def compact_other(out):
+    """`config.other`: [pictures/s of the sequential loop, encode_fps, decode_fps] of every workload measured beside the headline
+    one, keyed "ld" / "hts" / "htl" / "intra" at the default resolution and "uhd_<kind>" at 3840x2160 - a record of the other
+    models' numbers that survives a reader that keeps only the contract keys of the line."""
+    def row(o):
+        return [round(float(o[k]), 1) if o.get(k) is not None else None for k in ("value", "encode_fps", "decode_fps")]
+    other = {}
+    for kind, o in (out.get("other_workloads") or {}).items():
+        other[kind] = row(o)
+    for kind, o in (out.get("uhd") or {}).items():
+        if isinstance(o, dict) and "value" in o and kind in NAMES:
+            other["uhd_" + kind] = row(o)
+    for res, block in (out.get("resolutions") or {}).items():
+        for kind, o in block.items():
+            if isinstance(o, dict) and "value" in o:
+                other[res + "_" + kind] = row(o)
+    return other
+
+
+def ordered_line(out):
+    """The ONE JSON line with its long report blocks FIRST and the driver contract's keys LAST: a reader that keeps only the tail
+    of stdout (round 5: an 8 KB tail that began inside the `uhd` block) still sees metric / value / config / roofline."""
+    long_blocks = ("measurement_order", "fps_method", "loop", "data", "box", "uhd", "other_workloads", "resolutions", "pipelined",
+                   "sustained")
+    first = {k: out[k] for k in long_blocks if k in out}
+    rest = {k: v for k, v in out.items() if k not in first}
+    for k in ("cpu_baseline", "roofline", "config"):      # the structured contract blocks at the very end
+        if k in rest:
+            rest[k] = rest.pop(k)
+    first.update(rest)
+    return first
 
 
 def sweep64_block(env, kind, height, width, units):
@@ -1170,7 +1211,7 @@ def main():
     else:
         out = run_default(env, make_work)
     if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(ordered_line(out)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

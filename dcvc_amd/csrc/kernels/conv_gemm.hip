@@ -72,7 +72,8 @@ struct ConvGemmParams {
     // spatial description (k x k convs and the transposed conv)
     int in_h, in_w, out_h, out_w;   // input / output grid
     int cin, ksize, stride, pad;
-    int up_dy, up_dx;               // transposed conv: this launch writes pixel (2y+dy, 2x+dx)
+    int up_cout;                    // transposed conv: N = 4 * up_cout, channel tile n0 belongs to output pixel
+                                    // (2y + dy, 2x + dx) with dy * 2 + dx = n0 / up_cout (a tile never straddles two of them)
     long long* timeline;            // optional [blocks][16] shader-clock stamps of wave 0 (tools/gemm_timeline.py)
 };
 
@@ -454,8 +455,9 @@ conv_gemm_kernel(const ConvGemmParams p)
     __syncthreads();
     stamp();                                                       // 11: epilogue math done, tile in LDS
     // ---- whole-line stores: consecutive lanes write consecutive 16-B chunks of one pixel row
-    const int n0o = CHUNK ? (n0 >> 2) : n0;
-    const int nout = CHUNK ? (p.N >> 2) : p.N;
+    const int quad = UPSAMPLE ? n0 / p.up_cout : 0;          // transposed conv: which of the four output pixels
+    const int n0o = CHUNK ? (n0 >> 2) : (UPSAMPLE ? n0 - quad * p.up_cout : n0);
+    const int nout = CHUNK ? (p.N >> 2) : (UPSAMPLE ? p.up_cout : p.N);
 #pragma unroll
     for (int j = 0; j < OUNITS; ++j) {
         const int u = j * NTHREADS + tid;
@@ -465,7 +467,7 @@ conv_gemm_kernel(const ConvGemmParams p)
             size_t orow;
             if constexpr (UPSAMPLE) {
                 const int yy = m / p.in_w, xx = m - yy * p.in_w;
-                orow = static_cast<size_t>(2 * yy + p.up_dy) * (2 * p.in_w) + (2 * xx + p.up_dx);
+                orow = static_cast<size_t>(2 * yy + (quad >> 1)) * (2 * p.in_w) + (2 * xx + (quad & 1));
             } else {
                 orow = static_cast<size_t>(m);
             }
@@ -576,12 +578,14 @@ void launch(ConvGemmParams p, hipStream_t stream)
         default: break;
         }
     }
-    if (p.N % 256 == 0 && mt256 * (p.N / 256) >= 224) {
+    // (transposed conv: a channel tile must not straddle two output pixels - its width divides up_cout)
+    const int nq = UPSAMPLE ? p.up_cout : p.N;
+    if (nq % 256 == 0 && mt256 * (p.N / 256) >= 224) {
         launch_cfg<4, 2, 2, 4, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
         return;
     }
     if constexpr (!CHUNK) {
-        if (p.N % 192 == 0 && mt256 * (p.N / 192) >= 224) {
+        if (nq % 192 == 0 && mt256 * (p.N / 192) >= 224) {
             launch_cfg<4, 2, 2, 3, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
             return;
         }
@@ -743,19 +747,19 @@ void tconv2x2(const TConv2x2Desc& d, hipStream_t stream)
 {
     // out[2y+dy][2x+dx][co] = sum_ci x[y][x][ci] * w[(dy*2+dx)][co][ci]   (no bias: the reference
     // folds SubpelConv2x(kernel 1) into a stride-2 transposed conv, layers_proxy.cpp:320-323)
-    for (int dy = 0; dy < 2; ++dy)
-        for (int dx = 0; dx < 2; ++dx) {
-            ConvGemmParams p{};
-            p.x = d.x;  p.ldx = d.ldx;
-            p.w = d.w + static_cast<size_t>(dy * 2 + dx) * d.cout * d.cin;
-            p.bias = nullptr;
-            p.y = d.y;  p.ldy = d.ldy;
-            p.in_h = d.in_h; p.in_w = d.in_w;
-            p.up_dy = dy; p.up_dx = dx;
-            p.M = d.in_h * d.in_w; p.N = d.cout; p.K = d.cin;
-            check_common(p);
-            launch<false, ACT_NONE, false, 0, false, true>(p, stream);
-        }
+    // ONE launch (round 6; four until then): the four weight matrices are one [4 * cout][cin] matrix, a channel tile of the
+    // product belongs to one of the four output pixels and is scattered there by the epilogue's whole-line stores.
+    if (d.cout % 128 != 0) throw std::invalid_argument("tconv2x2: cout must be a multiple of 128 (one channel tile per output pixel)");
+    ConvGemmParams p{};
+    p.x = d.x;  p.ldx = d.ldx;
+    p.w = d.w;
+    p.bias = nullptr;
+    p.y = d.y;  p.ldy = d.ldy;
+    p.in_h = d.in_h; p.in_w = d.in_w;
+    p.up_cout = d.cout;
+    p.M = d.in_h * d.in_w; p.N = 4 * d.cout; p.K = d.cin;
+    check_common(p);
+    launch<false, ACT_NONE, false, 0, false, true>(p, stream);
 }
 
 }  // namespace dcvc
