@@ -98,12 +98,13 @@ private:
     DcbW m_henc0, m_hdec2;
     Stride2W m_henc1, m_henc2, m_tpe;
     UpsampleW m_hdec0, m_hdec1;
-    Conv1x1W m_fus3, m_reduction, m_sp3;
+    FinW m_fus3, m_sp3;        // the convs that close the fusion / spatial prior chains
+    Conv1x1W m_reduction;
     DcbW m_sp_adaptor[3];
     SubpelW m_dec_up;
     DcbW m_rh_common[kFrames / 2];          // HT-S: recon_head.conv1.i.0
     DcbChain m_rh[kFrames];                 // HT-S: recon_head.conv2.i.{0,1,2}; HT-L: recon_head.conv.i.{0..4}
-    Conv1x1W m_rh_head[kFrames];
+    FinW m_rh_head[kFrames];
     float m_skip_thres = 0.f;
     bool m_has_params = false;
 

@@ -79,7 +79,7 @@ void DmcHtCodec::set_param(const ParamStore& ps, float skip_thres)
             m_rh_head[i].load(ps, m_wmem, "recon_head.conv." + n + "." + std::to_string(m_rh[i].size()) + ".");
         }
     }
-    if (m_sp3.cout != (m_hts ? kChY : 2 * kChY)) throw std::invalid_argument("unexpected y_spatial_prior.conv.3 width");
+    if (m_sp3.conv.cout != (m_hts ? kChY : 2 * kChY)) throw std::invalid_argument("unexpected y_spatial_prior.conv.3 width");
     load_cdf_tables(ps);
     m_has_params = true;
     m_has_ref = m_enc_ready = m_memory_has_value = m_has_feature_p = false;
@@ -218,11 +218,8 @@ void DmcHtCodec::run_common(hipStream_t st)
     m_hdec2.forward(h2, View(m_HP, kChY, kChY), g.H16p, g.W16p, m_s, st);
     crop(m_HP, kChY, g.W16p, m_CATPF, 3 * kChY, g.H16, g.W16, kChY, st);       // crop_hyper_params
     const View pf(m_CATPF, 3 * kChY, 3 * kChY);
-    m_fus.forward(pf, pf, pf, g.H16, g.W16, m_s, st);
-    Conv1x1Desc d;
-    d.x = m_CATPF; d.ldx = 3 * kChY; d.w = m_fus3.w; d.bias = m_fus3.b;
-    d.y = m_COMMON; d.ldy = 3 * kChY; d.pixels = g.P16(); d.cin = 3 * kChY; d.cout = 3 * kChY;
-    conv1x1(d, st);
+    const FinCall fin(m_fus3, m_COMMON, 3 * kChY);          // y_prior_fusion.conv.3 closes the chain
+    m_fus.forward(pf, pf, pf, g.H16, g.W16, m_s, st, nullptr, View(), &fin);
 }
 
 void DmcHtCodec::run_reduction(hipStream_t st)
@@ -238,11 +235,8 @@ void DmcHtCodec::run_spatial_prior(int k, hipStream_t st)
     const Geometry& g = m_g;
     const View ad(m_AD, 2 * kChY, 2 * kChY);
     m_sp_adaptor[k].forward(View(m_CATSP, 2 * kChY, 2 * kChY), ad, g.H16, g.W16, m_s, st);
-    m_sp.forward(ad, ad, ad, g.H16, g.W16, m_s, st);
-    Conv1x1Desc d;
-    d.x = m_AD; d.ldx = 2 * kChY; d.w = m_sp3.w; d.bias = m_sp3.b;
-    d.y = m_SP; d.ldy = m_sp3.cout; d.pixels = g.P16(); d.cin = 2 * kChY; d.cout = m_sp3.cout;
-    conv1x1(d, st);
+    const FinCall fin(m_sp3, m_SP, m_sp3.conv.cout);       // y_spatial_prior.conv.3 closes the chain
+    m_sp.forward(ad, ad, ad, g.H16, g.W16, m_s, st, nullptr, View(), &fin);
 }
 
 void DmcHtCodec::run_decoder(hipStream_t st)
@@ -272,12 +266,9 @@ void DmcHtCodec::run_recon_head(half_t* x_hat, hipStream_t st)
             trunk_done = true;
             trunk = rc;
         }
-        m_rh[i].forward(trunk, rt, rt, g.H8, g.W8, m_s, st);
         half_t* head = (i == kFrames - 1) ? m_FI : m_RH;    // the last head output doubles as the reset feature
-        Conv1x1Desc d;
-        d.x = m_RT; d.ldx = kChRecon; d.w = m_rh_head[i].w; d.bias = m_rh_head[i].b;
-        d.y = head; d.ldy = kChSrcI; d.pixels = g.P8(); d.cin = kChRecon; d.cout = kChSrcI;
-        conv1x1(d, st);
+        const FinCall fin(m_rh_head[i], head, kChSrcI);     // the head conv closes the chain
+        m_rh[i].forward(trunk, rt, rt, g.H8, g.W8, m_s, st, nullptr, View(), &fin);
         shuffle8(head, kChSrcI, g.H8, g.W8, 3, true, x_hat + i * picture, st);
     }
 }
@@ -294,11 +285,8 @@ void DmcHtCodec::run_recon_reset(hipStream_t st)
         m_rh_common[i / 2].forward(feature, rc, g.H8, g.W8, m_s, st);
         trunk = rc;
     }
-    m_rh[i].forward(trunk, rt, rt, g.H8, g.W8, m_s, st);
-    Conv1x1Desc d;
-    d.x = m_RT; d.ldx = kChRecon; d.w = m_rh_head[i].w; d.bias = m_rh_head[i].b;
-    d.y = m_FI; d.ldy = kChSrcI; d.pixels = g.P8(); d.cin = kChRecon; d.cout = kChSrcI;
-    conv1x1(d, st);
+    const FinCall fin(m_rh_head[i], m_FI, kChSrcI);
+    m_rh[i].forward(trunk, rt, rt, g.H8, g.W8, m_s, st, nullptr, View(), &fin);
 }
 
 // ------------------------------------------------------------------------------------ reference frame

@@ -73,7 +73,7 @@ private:
     half_t *m_cur_q_encoder = nullptr, *m_cur_q_decoder = nullptr, *m_cur_q_feature = nullptr;
     half_t* m_zeros = nullptr;
     DcbW m_fa_i[4], m_fa_m[4], m_fe[5];
-    DcbW m_enc1[2], m_enc2;
+    DcbW m_encb[3];               // encoder.conv1.0, .1 and encoder.conv2: one chain of three blocks, the last with the quant scale
     ConvKW m_enc_down;
     DcbW m_henc0;
     Stride2W m_henc1, m_henc2;
@@ -81,14 +81,14 @@ private:
     DcbW m_hdec2;
     Stride2W m_tpe;
     DcbW m_fus[3];
-    Conv1x1W m_fus3;
+    FinW m_fus3;
     DcbW m_sp[2];
-    Conv1x1W m_sp2;
+    FinW m_sp2;
     SubpelW m_dec_up;
     DcbW m_dec1[3];
-    Conv1x1W m_dec2;
+    FinW m_dec2;
     DcbW m_rh[3];
-    Conv1x1W m_rh_head;
+    FinW m_rh_head;
     float m_skip_thres = 0.f;
     bool m_has_params = false;
 

@@ -54,8 +54,8 @@ void DmcLdCodec::set_param(const ParamStore& ps, float skip_thres)
     chain(m_fa_i, 4, "feature_adaptor_i.conv.");
     chain(m_fa_m, 4, "feature_adaptor_m.conv.");
     chain(m_fe, 5, "feature_extractor.conv.");
-    chain(m_enc1, 2, "encoder.conv1.");
-    m_enc2.load(ps, m_wmem, "encoder.conv2.");
+    chain(m_encb, 2, "encoder.conv1.");
+    m_encb[2].load(ps, m_wmem, "encoder.conv2.");
     m_enc_down.load(ps, m_wmem, "encoder.down.");
     m_henc0.load(ps, m_wmem, "hyper_encoder.conv.0.");
     m_henc1.load(ps, m_wmem, "hyper_encoder.conv.1.", false);      // dmc_ld_proxy.cpp:250-251
@@ -168,9 +168,10 @@ void DmcLdCodec::run_encoder(hipStream_t st)
     const Geometry& g = m_g;
     const View t(m_T, kChD, kChD);
     // [x unshuffled | ctx] = channels 64..511 of CATD (dmc_ld_proxy.cpp:755-757)
-    run_dcb_chain(m_enc1, 2, View(m_CATD + 64, kChD + kChM, kChSrc + kChM), t, t, g.H8, g.W8, m_s, st, nullptr,
+    // encoder.conv1 (two blocks) and encoder.conv2 (its output scaled by q_encoder inside its last conv) as ONE chain: every
+    // launch also computes dc.0 of the block behind it
+    run_dcb_chain(m_encb, 3, View(m_CATD + 64, kChD + kChM, kChSrc + kChM), t, t, g.H8, g.W8, m_s, st, m_cur_q_encoder,
                   View(m_T2, kChD, kChD));
-    m_enc2.forward(t, t, g.H8, g.W8, m_s, st, false, m_cur_q_encoder);
     ConvKxKDesc d;
     d.x = m_T; d.ldx = kChD; d.w = m_enc_down.w; d.bias = m_enc_down.b; d.zeros = m_zeros;
     d.y = m_Y; d.ldy = kChY; d.in_h = g.H8; d.in_w = g.W8; d.cin = kChD; d.cout = kChY;
@@ -202,23 +203,18 @@ void DmcLdCodec::run_priors(hipStream_t st)
     crop(m_HP, kChY, g.W16p, m_CATPF, 3 * kChY, g.H16, g.W16, kChY, st);
     mul_channel(m_CATPF + kChY, 3 * kChY, m_cur_q_feature, m_CATPF + kChY, 3 * kChY, g.P16(), 2 * kChY, st);
     const View pf(m_CATPF, 3 * kChY, 3 * kChY);
-    for (int i = 0; i < 3; ++i) m_fus[i].forward(pf, pf, g.H16, g.W16, m_s, st);
-    Conv1x1Desc d;      // -> (q_dec | scales | means) behind y_hat in the spatial-prior input
-    d.x = m_CATPF; d.ldx = 3 * kChY; d.w = m_fus3.w; d.bias = m_fus3.b;
-    d.y = m_CATSP + kChY; d.ldy = 4 * kChY; d.pixels = g.P16(); d.cin = 3 * kChY; d.cout = 3 * kChY;
-    conv1x1(d, st);
+    // y_prior_fusion: three (384, 192) blocks in place, each launch with dc.0 of the next inside, the last one with
+    // y_prior_fusion.conv.3 -> (q_dec | scales | means) behind y_hat in the spatial-prior input
+    const FinCall fin(m_fus3, m_CATSP + kChY, 4 * kChY);
+    run_dcb_chain(m_fus, 3, pf, pf, pf, g.H16, g.W16, m_s, st, nullptr, View(), &fin);
 }
 
 void DmcLdCodec::run_spatial_prior(hipStream_t st)
 {
     const Geometry& g = m_g;
     const View t(m_SPT, 2 * kChY, 2 * kChY);
-    m_sp[0].forward(View(m_CATSP, 4 * kChY, 4 * kChY), t, g.H16, g.W16, m_s, st);
-    m_sp[1].forward(t, t, g.H16, g.W16, m_s, st);
-    Conv1x1Desc d;
-    d.x = m_SPT; d.ldx = 2 * kChY; d.w = m_sp2.w; d.bias = m_sp2.b;
-    d.y = m_MEANS1; d.ldy = kChY; d.pixels = g.P16(); d.cin = 2 * kChY; d.cout = kChY;
-    conv1x1(d, st);
+    const FinCall fin(m_sp2, m_MEANS1, kChY);              // y_spatial_prior.conv.2 closes the chain
+    run_dcb_chain(m_sp, 2, View(m_CATSP, 4 * kChY, 4 * kChY), t, t, g.H16, g.W16, m_s, st, nullptr, View(), &fin);
 }
 
 void DmcLdCodec::run_decoder(hipStream_t st)
@@ -226,24 +222,19 @@ void DmcLdCodec::run_decoder(hipStream_t st)
     const Geometry& g = m_g;
     m_dec_up.forward(View(m_CATSP, 4 * kChY, kChY), View(m_CATD, kChD + kChM, kChD), g.H16, g.W16, st);
     const View t(m_T, kChD, kChD);
+    // decoder.conv2 (conv1x1_bias_with_quant) closes the chain -> feature_p, second half of the adaptor_m input
+    const FinCall fin(m_dec2, m_CATM + kChM, kChM + kChD, m_cur_q_decoder);
     run_dcb_chain(m_dec1, 3, View(m_CATD, kChD + kChM, kChD + kChM), t, t, g.H8, g.W8, m_s, st, nullptr,
-                  View(m_T2, kChD, kChD));
-    Conv1x1Desc d;      // conv1x1_bias_with_quant -> feature_p, second half of the adaptor_m input
-    d.x = m_T; d.ldx = kChD; d.w = m_dec2.w; d.bias = m_dec2.b; d.q = m_cur_q_decoder;
-    d.y = m_CATM + kChM; d.ldy = kChM + kChD; d.pixels = g.P8(); d.cin = kChD; d.cout = kChD;
-    conv1x1(d, st);
+                  View(m_T2, kChD, kChD), &fin);
 }
 
 void DmcLdCodec::run_recon_head(half_t* x_hat, hipStream_t st)
 {
     const Geometry& g = m_g;
     const View t(m_T, kChD, kChD);
+    const FinCall fin(m_rh_head, m_FI, kChSrc);            // the head output doubles as the reference feature after a reset
     run_dcb_chain(m_rh, 3, View(m_CATM + kChM, kChM + kChD, kChD), t, t, g.H8, g.W8, m_s, st, nullptr,
-                  View(m_T2, kChD, kChD));
-    Conv1x1Desc d;      // the head output doubles as the reference feature after a reset
-    d.x = m_T; d.ldx = kChD; d.w = m_rh_head.w; d.bias = m_rh_head.b;
-    d.y = m_FI; d.ldy = kChSrc; d.pixels = g.P8(); d.cin = kChD; d.cout = kChSrc;
-    conv1x1(d, st);
+                  View(m_T2, kChD, kChD), &fin);
     if (x_hat != nullptr) shuffle8(m_FI, kChSrc, g.H8, g.W8, 3, true, x_hat, st);
 }
 

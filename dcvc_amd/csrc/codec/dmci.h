@@ -66,9 +66,10 @@ private:
     UpsampleW m_hdec0, m_hdec1;
     DcbW m_hdec2;
     DcbW m_fus[3];
-    Conv1x1W m_fus3, m_reduction;
+    FinW m_fus3;               // y_prior_fusion.conv.3: closes the fusion chain (inside its last block launch)
+    Conv1x1W m_reduction;
     DcbW m_sp_adaptor[3], m_sp[3];
-    Conv1x1W m_sp3;
+    FinW m_sp3;                // y_spatial_prior.conv.3: closes the spatial prior chain
     UpsampleW m_dec_up;
     DcbW m_dec1[12], m_dec2;
     float m_skip_thres = 0.f;

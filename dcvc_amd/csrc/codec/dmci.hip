@@ -176,13 +176,9 @@ void DmciCodec::run_priors_from_zhat(hipStream_t st)
         const DcbW* n2 = m_fus[1].feeds(m_fus[2]) ? &m_fus[2] : nullptr;
         m_fus[0].forward(View(m_HP, kChY, kChY), pf, g.H16p, g.W16p, m_s, st, false, nullptr, nullptr, View(), n1, false);
         m_fus[1].forward(pf, pf, g.H16p, g.W16p, m_s, st, false, nullptr, nullptr, View(), n2, n1 != nullptr);
-        m_fus[2].forward(pf, pf, g.H16p, g.W16p, m_s, st, false, nullptr, nullptr, View(), nullptr, n2 != nullptr);
-    }
-    {
-        Conv1x1Desc d;
-        d.x = m_PF; d.ldx = 2 * kChY; d.w = m_fus3.w; d.bias = m_fus3.b;
-        d.y = m_PARAMSp; d.ldy = 2 * kChY; d.pixels = g.P16p(); d.cin = 2 * kChY; d.cout = 2 * kChY;
-        conv1x1(d, st);
+        // ... and the last one the conv that closes the chain (y_prior_fusion.conv.3 -> params)
+        const FinCall fin(m_fus3, m_PARAMSp, 2 * kChY);
+        m_fus[2].forward(pf, pf, g.H16p, g.W16p, m_s, st, false, nullptr, nullptr, View(), nullptr, n2 != nullptr, &fin);
     }
     if (g.padded()) {
         crop(m_PARAMSp, 2 * kChY, g.W16p, m_PARAMS, 2 * kChY, g.H16, g.W16, 2 * kChY, st);
@@ -204,12 +200,9 @@ void DmciCodec::run_spatial_prior(int k, hipStream_t st)
     for (int i = 0; i < 3; ++i) {
         const bool handed = next != nullptr;
         next = (i < 2 && m_sp[i].feeds(m_sp[i + 1])) ? &m_sp[i + 1] : nullptr;
-        m_sp[i].forward(ad, ad, g.H16, g.W16, m_s, st, false, nullptr, nullptr, View(), next, handed);
+        const FinCall fin(m_sp3, m_SP, 2 * kChY);          // y_spatial_prior.conv.3 closes the chain
+        m_sp[i].forward(ad, ad, g.H16, g.W16, m_s, st, false, nullptr, nullptr, View(), next, handed, i == 2 ? &fin : nullptr);
     }
-    Conv1x1Desc d;
-    d.x = m_AD; d.ldx = 2 * kChY; d.w = m_sp3.w; d.bias = m_sp3.b;
-    d.y = m_SP; d.ldy = 2 * kChY; d.pixels = g.P16(); d.cin = 2 * kChY; d.cout = 2 * kChY;
-    conv1x1(d, st);
 }
 
 void DmciCodec::run_decoder(half_t* x_hat, hipStream_t st)

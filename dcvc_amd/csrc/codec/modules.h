@@ -82,6 +82,22 @@ struct Conv1x1W {
     void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
 };
 
+// The 1x1 conv that closes a chain of blocks (y_prior_fusion.conv.3, y_spatial_prior.conv.3, decoder.conv2, recon_head.head
+// ...: launches of their own in the reference, dmci_proxy.cpp:145-199, dmc_ld_proxy.cpp:420-593). Where the block kernel has
+// the variant it runs in the NEXT slot of the chain's last block launch (kernels/dcb_nsplit8_kernel.h), else behind it.
+struct FinW {
+    Conv1x1W conv;
+    half_t* packed = nullptr;        // dcb_nsplit_pack_fin stream (for a last block of width conv.cin) or null
+    void load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix);
+};
+struct FinCall {
+    const FinW* w = nullptr;
+    const half_t* q = nullptr;       // conv1x1_bias_with_quant's scale or null
+    half_t* y = nullptr; int ldy = 0;
+    FinCall() = default;
+    FinCall(const FinW& w_, half_t* y_, int ldy_, const half_t* q_ = nullptr) : w(&w_), q(q_), y(y_), ldy(ldy_) {}
+};
+
 // layers.py:128-159 DepthConvBlock; layers_proxy.cpp:160-206 for the folding
 struct DcbW {
     bool has_adaptor = false;
@@ -101,9 +117,11 @@ struct DcbW {
     // launch, which can also compute dc.0 of the block that FOLLOWS in a chain:
     // `next` = that block (must satisfy feeds(next)), its dc.0 output then waits in s.t1 and the
     // caller passes dc0_done = true to next->forward().
+    // `fin`: the conv that closes the chain this block is the last of: yfin = conv(y) - inside the block launch where the
+    // kernel has the variant, as a launch of its own behind it otherwise (the caller never launches it)
     void forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut = false,
                  const half_t* q_fused = nullptr, const half_t* q_after = nullptr, View alt = View(),
-                 const DcbW* next = nullptr, bool dc0_done = false) const;
+                 const DcbW* next = nullptr, bool dc0_done = false, const FinCall* fin = nullptr) const;
     bool core_fused() const;                     // this block runs through dcb_nsplit
     bool nsplit() const { return packed_main != nullptr; }
     bool feeds(const DcbW& next) const;          // ... and can compute next's dc.0 on the way out
@@ -156,13 +174,13 @@ struct DcbChain {
     // into the last block (DepthConvBlockProxy::forward(x, quant), layers_proxy.cpp:92-95).
     // With a second temporary the blocks ping-pong between the two instead of running in place.
     void forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
-                 const half_t* q_fused_last = nullptr, View tmp2 = View()) const;
+                 const half_t* q_fused_last = nullptr, View tmp2 = View(), const FinCall* fin = nullptr) const;
     size_t size() const { return blocks.size(); }
 };
 
 // the same launch sequence over a plain array of blocks (codecs that keep DcbW[n] members)
 void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, int W, const Scratch& s,
-                   hipStream_t st, const half_t* q_fused_last = nullptr, View tmp2 = View());
+                   hipStream_t st, const half_t* q_fused_last = nullptr, View tmp2 = View(), const FinCall* fin = nullptr);
 
 // dense k x k conv weight in tap-major layout
 struct ConvKW {

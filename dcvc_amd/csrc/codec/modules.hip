@@ -117,6 +117,29 @@ void ConvKW::load(const ParamStore& ps, DeviceArena& mem, const std::string& pre
     b = ps.has(prefix + "bias") ? mem.upload(ps.at(prefix + "bias").h) : nullptr;
 }
 
+void FinW::load(const ParamStore& ps, DeviceArena& mem, const std::string& prefix)
+{
+    conv.load(ps, mem, prefix);
+    packed = nullptr;
+    if (conv.b != nullptr && conv.cin % 128 == 0 && conv.cout % 32 == 0 && conv.cout >= 128 && dcb_nsplit_waves() == 8) {
+        packed = mem.alloc_half(dcb_nsplit_fin_halves(conv.cin, conv.cout));
+        dcb_nsplit_pack_fin(conv.w, conv.cin, conv.cout, packed, nullptr);
+        hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(pack)");
+    }
+}
+
+namespace {
+
+void run_fin(const FinCall& f, View x, int pixels, hipStream_t st)
+{
+    Conv1x1Desc d;
+    d.x = x.p; d.ldx = x.ld; d.w = f.w->conv.w; d.bias = f.w->conv.b; d.q = f.q;
+    d.y = f.y; d.ldy = f.ldy; d.pixels = pixels; d.cin = f.w->conv.cin; d.cout = f.w->conv.cout;
+    conv1x1(d, st);
+}
+
+}  // namespace
+
 void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
 {
     has_adaptor = ps.has(p + "adaptor.weight");
@@ -180,9 +203,12 @@ bool DcbW::feeds(const DcbW& next) const
 }
 
 void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t st, bool shortcut,
-                   const half_t* q_fused, const half_t* q_after, View alt, const DcbW* next, bool dc0_done) const
+                   const half_t* q_fused, const half_t* q_after, View alt, const DcbW* next, bool dc0_done, const FinCall* fin) const
 {
     const int P = H * W;
+    if (fin != nullptr && (next != nullptr || fin->w == nullptr || fin->w->conv.cin != c)) {
+        throw std::invalid_argument("DepthConvBlock: a closing conv sits behind the LAST block of a chain and reads its output");
+    }
     if ((next != nullptr && !feeds(*next)) || (dc0_done && (!core_fused() || has_adaptor))) {
         throw std::invalid_argument("DepthConvBlock: dc.0 hand-over between blocks that do not support it");
     }
@@ -194,7 +220,12 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         // the adaptor output would have to survive the in-place dc.3 / ffn.2 updates
         throw std::invalid_argument("DepthConvBlock with adaptor and shortcut is not a DCVC-UF block");
     }
+    const bool tail = !nsplit() && dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr &&
+                      dc3.b != nullptr && dc0.b != nullptr;
     if (has_adaptor) {
+        // the one-launch block (dcb_tail with dc.0 inside) reads its input's neighbours, so the adaptor output must not be
+        // the block output: without a spare buffer from the caller it goes to the third scratch plane, which that launch leaves alone
+        if (alt.p == nullptr && tail && static_cast<size_t>(P) * c <= s.elems) alt = View(s.t3, c, c);
         const View a = (alt.p != nullptr && alt.p != y.p) ? View(alt.p, alt.ld, c) : y;
         Conv1x1Desc d;
         d.x = x.p; d.ldx = x.ld; d.w = adaptor.w; d.bias = adaptor.b;
@@ -204,8 +235,6 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
     } else if (shortcut && x.p == y.p) {
         throw std::invalid_argument("DepthConvBlock with shortcut cannot run in place");
     }
-    const bool tail = !nsplit() && dcb_tail_supported(H, W, c, cdc, cffn) && ffn0.b != nullptr && ffn2.b != nullptr &&
-                      dc3.b != nullptr && dc0.b != nullptr;
     const bool tail_dc0 = tail && dcb_tail_takes_dc0() && in.p != y.p;      // reads neighbours' input: not in place
     if (!tail_dc0 && !dc0_done) {   // dc.0 + WSiLU
         Conv1x1Desc d;
@@ -222,6 +251,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld;
         d.H = H; d.W = W; d.c = c; d.cdc = cdc; d.cffn = cffn; d.shortcut = shortcut;
         dcb_tail(d, st);
+        if (fin != nullptr) run_fin(*fin, y, P, st);
         return;
     }
     dwconv3x3(s.t1, cdc, dw, s.t2, cdc, H, W, cdc, st);
@@ -234,7 +264,13 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         if (next != nullptr) {
             d.wnext = next->packed_dc0; d.b1n = next->dc0.b; d.t1n = s.t1; d.ldt1 = next->cdc;
         }
+        const bool fin_inside = fin != nullptr && fin->w->packed != nullptr && dcb_nsplit_fin_supported(c, cdc, fin->w->conv.cout);
+        if (fin_inside) {
+            d.wfin = fin->w->packed; d.bfin = fin->w->conv.b; d.qfin = fin->q; d.yfin = fin->y; d.ldyfin = fin->ldy;
+            d.nfin = fin->w->conv.cout;
+        }
         dcb_nsplit(d, st);
+        if (fin != nullptr && !fin_inside) run_fin(*fin, y, P, st);
         return;
     }
     {   // dc.3 (+ folded depthwise bias) + shortcut
@@ -251,6 +287,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         d.q = q_fused; d.q2 = q_after;
         d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.cffn = cffn;
         ffn_fused(d, st);
+        if (fin != nullptr) run_fin(*fin, y, P, st);
         return;
     }
     {   // ffn.0 + WSiLU + chunk-add: the 4x expanded tensor never reaches HBM
@@ -267,6 +304,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         d.y = y.p; d.ldy = y.ld; d.pixels = P; d.cin = cffn; d.cout = c;
         conv1x1(d, st);
     }
+    if (fin != nullptr) run_fin(*fin, y, P, st);
 }
 
 void Stride2W::load(const ParamStore& ps, DeviceArena& mem, const std::string& p, bool with_shortcut)
@@ -373,7 +411,7 @@ void DcbChain::load(const ParamStore& ps, DeviceArena& mem, const std::string& p
 }
 
 void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, int W, const Scratch& s,
-                   hipStream_t st, const half_t* q_fused_last, View tmp2)
+                   hipStream_t st, const half_t* q_fused_last, View tmp2, const FinCall* fin)
 {
     if (tmp2.p == nullptr) {
         View cur = x;
@@ -382,7 +420,7 @@ void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, i
             const View out = (i == n - 1) ? y : tmp;
             const DcbW* next = (i + 1 < n && blocks[i].feeds(blocks[i + 1])) ? &blocks[i + 1] : nullptr;
             blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr, nullptr, View(),
-                              next, handed);
+                              next, handed, i == n - 1 ? fin : nullptr);
             handed = next != nullptr;
             cur = out;
         }
@@ -403,16 +441,16 @@ void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, i
         const View spare = (out.p == a.p) ? b : a;              // for an adaptor: neither input nor output
         const DcbW* next = (i + 1 < n && blocks[i].feeds(blocks[i + 1])) ? &blocks[i + 1] : nullptr;
         blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr, nullptr,
-                          cur.p == spare.p ? View() : spare, next, handed);
+                          cur.p == spare.p ? View() : spare, next, handed, i == n - 1 ? fin : nullptr);
         handed = next != nullptr;
         cur = out;
     }
 }
 
 void DcbChain::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
-                       const half_t* q_fused_last, View tmp2) const
+                       const half_t* q_fused_last, View tmp2, const FinCall* fin) const
 {
-    run_dcb_chain(blocks.data(), static_cast<int>(blocks.size()), x, tmp, y, H, W, s, st, q_fused_last, tmp2);
+    run_dcb_chain(blocks.data(), static_cast<int>(blocks.size()), x, tmp, y, H, W, s, st, q_fused_last, tmp2, fin);
 }
 
 }  // namespace dcvc

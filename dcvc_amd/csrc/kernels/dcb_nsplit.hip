@@ -50,8 +50,9 @@ __global__ void pack_dc0_kernel(const half_t* w1, int C, int CI, half8* out)    
 // [simd QC, (simd + 1) QC) of a C-wide layer (w the first HI, w + 4 the remaining LO); ffn.0: N0 tiles per wave in passes of 2
 __global__ void pack_main8_kernel(const half_t* w3, const half_t* w0, const half_t* w2, int C, int CI, half8* out)
 {
-    const int KS_C = C / 16, KS_I = CI / 16, QC = C / 128, HI_C = (QC + 1) / 2, LO_C = QC / 2, N0 = CI / 64, TP = 2;
-    const int F_FFN0 = N0 * KS_C, FM_HI = 2 * HI_C * KS_I + F_FFN0, FM_LO = 2 * LO_C * KS_I + F_FFN0;
+    const int KS_C = C / 16, KS_I = CI / 16, QC = C / 128, HI_C = (QC + 1) / 2, LO_C = QC / 2, TP = 2;
+    const int PAIRS = CI / 16, P0_HI = (PAIRS + 7) / 8, P0_LO = (PAIRS - 4 * P0_HI) / 4;       // Geo<>: ffn.0 tile pairs per wave (CI = 192: 2 | 1)
+    const int FM_HI = 2 * HI_C * KS_I + 2 * P0_HI * KS_C, FM_LO = 2 * LO_C * KS_I + 2 * P0_LO * KS_C;
     const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (u >= 4LL * (FM_HI + FM_LO) * 64) return;
     const int lane = static_cast<int>(u & 63);
@@ -59,15 +60,16 @@ __global__ void pack_main8_kernel(const half_t* w3, const half_t* w0, const half
     const bool hiw = F < 4 * FM_HI;
     const int wave = hiw ? F / FM_HI : 4 + (F - 4 * FM_HI) / FM_LO;
     const int f = hiw ? F % FM_HI : (F - 4 * FM_HI) % FM_LO;
-    const int simd = wave & 3, NT = hiw ? HI_C : LO_C, F_DC3 = NT * KS_I;
+    const int simd = wave & 3, NT = hiw ? HI_C : LO_C, F_DC3 = NT * KS_I, F_FFN0 = 2 * (hiw ? P0_HI : P0_LO) * KS_C;
     const int cb = 32 * (simd * QC + (hiw ? 0 : HI_C));
+    const int cb0 = hiw ? wave * 64 * P0_HI : 4 * 64 * P0_HI + (wave - 4) * 64 * P0_LO;       // the wave's first ffn.0 channel
     const half_t* w;
     int n0, ks, K;
     if (f < F_DC3) {                                  // dc.3 [C][CI]
         ks = f / NT; n0 = cb + 32 * (f % NT); w = w3; K = CI;
     } else if (f < F_DC3 + F_FFN0) {                  // ffn.0 [4 CI][C]
         const int g = f - F_DC3, pass = g / (TP * KS_C), r = g % (TP * KS_C);
-        ks = r / TP; n0 = wave * 32 * N0 + pass * 32 * TP + 32 * (r % TP); w = w0; K = C;
+        ks = r / TP; n0 = cb0 + pass * 32 * TP + 32 * (r % TP); w = w0; K = C;
     } else {                                          // ffn.2 [C][CI]
         const int g = f - F_DC3 - F_FFN0;
         ks = g / NT; n0 = cb + 32 * (g % NT); w = w2; K = CI;
@@ -90,6 +92,26 @@ __global__ void pack_dc08_kernel(const half_t* w1, int C, int CI, half8* out)   
     out[u] = *reinterpret_cast<const half8*>(w1 + static_cast<size_t>(n0 + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5));
 }
 
+// the closing conv of a chain in the 8-wave kernel's NEXT slot, [NN][C]: waves 0 .. 3 own nf_hi tiles each, of the waves 4 .. 7
+// the first act_lo own nf_lo each (Geo<>::nf_hi / nf_lo / act_lo); the streams of idle waves stay zero
+__global__ void pack_fin8_kernel(const half_t* w, int C, int NN, half8* out)
+{
+    const int KS_C = C / 16, TN = NN / 32, HI = (TN + 7) / 8, REM = TN - 4 * HI, LO = REM <= 0 ? 0 : (REM + 3) / 4, ACT = LO == 0 ? 0 : REM / LO;
+    const int FD_HI = HI * KS_C, FD_LO = LO * KS_C;
+    const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (u >= 4LL * (FD_HI + FD_LO) * 64) return;
+    const int lane = static_cast<int>(u & 63);
+    const int F = static_cast<int>(u >> 6);
+    const bool hiw = F < 4 * FD_HI;
+    const int wave = hiw ? F / FD_HI : 4 + (F - 4 * FD_HI) / FD_LO;
+    const int f = hiw ? F % FD_HI : (F - 4 * FD_HI) % FD_LO;
+    const int NT = hiw ? HI : LO;
+    const int ks = f / NT, tile = (hiw ? wave * HI : 4 * HI + (wave - 4) * LO) + f % NT;
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hiw || wave - 4 < ACT) v = *reinterpret_cast<const half8*>(w + static_cast<size_t>(32 * tile + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5));
+    out[u] = v;
+}
+
 long long* g_ns_timeline = nullptr;
 
 }  // namespace
@@ -99,7 +121,21 @@ int dcb_nsplit_waves();
 bool dcb_nsplit_shape(int c, int ci)
 {
     return (c == 384 && ci == 384) || (c == 512 && ci == 512) || (c == 768 && ci == 768) || (c == 256 && ci == 256) ||
-           (c == 512 && ci == 256) || (c == 256 && ci == 128);
+           (c == 512 && ci == 256) || (c == 256 && ci == 128) ||
+           (c == 384 && ci == 192 && dcb_nsplit_waves() == 8);       // round 6: the LD model's prior fusion blocks (8-wave kernel only)
+}
+
+// widths of a chain-closing conv the 8-wave kernel of a block shape is instantiated for (dcb_nsplit8_<shape>_fin.hip)
+bool dcb_nsplit_fin_supported(int c, int ci, int nn)
+{
+    static const bool off = [] { const char* e = getenv("DCVC_NSPLIT_FIN"); return e != nullptr && atoi(e) == 0; }();   // A/B: the closing convs as launches of their own
+    if (off || dcb_nsplit_waves() != 8 || !dcb_nsplit_shape(c, ci)) return false;
+    if (c == 256 && ci == 128) return nn == 128 || nn == 192 || nn == 256;
+    if (c == 256 && ci == 256) return nn == 192;
+    if (c == 512 && ci == 512) return nn == 256 || nn == 512;
+    if (c == 768 && ci == 768) return nn == 768;
+    if (c == 384 && ci == 192) return nn == 384;
+    return false;
 }
 
 void dcb_nsplit_timeline_buffer(long long* device_buffer)
@@ -107,8 +143,27 @@ void dcb_nsplit_timeline_buffer(long long* device_buffer)
     g_ns_timeline = device_buffer;
 }
 
-size_t dcb_nsplit_main_halves(int c, int ci) { return 4ull * (2 * (c / 128) * (ci / 16) + (ci / 128) * 4 * (c / 16)) * 512; }
-size_t dcb_nsplit_dc0_halves(int c, int ci) { return 4ull * ((ci / 128) * (c / 16)) * 512; }
+// fragments of 512 halves: dc.3 and ffn.2 (c / 32 tiles x ci / 16 slices each), ffn.0 (4 ci / 32 tiles x c / 16 slices)
+size_t dcb_nsplit_main_halves(int c, int ci) { return (2ull * (c / 32) * (ci / 16) + 1ull * (ci / 8) * (c / 16)) * 512; }
+size_t dcb_nsplit_dc0_halves(int c, int ci)
+{
+    // an inner width that is no multiple of 128 (192): tiles by wave as a closing conv's, with the streams of the idle waves
+    return ci % 128 == 0 ? 1ull * (ci / 32) * (c / 16) * 512 : dcb_nsplit_fin_halves(c, ci);
+}
+
+size_t dcb_nsplit_fin_halves(int c, int nn)      // (declared in ops.h)
+{
+    const int tn = nn / 32, hi = (tn + 7) / 8, rem = tn - 4 * hi, lo = rem <= 0 ? 0 : (rem + 3) / 4;
+    return 4ull * (hi + lo) * (c / 16) * 512;
+}
+
+void dcb_nsplit_pack_fin(const half_t* w, int c, int nn, half_t* out, hipStream_t stream)
+{
+    if (nn % 32 != 0 || nn < 128 || c % 128 != 0) throw std::invalid_argument("dcb_nsplit: unsupported closing conv");
+    const long long units = static_cast<long long>(dcb_nsplit_fin_halves(c, nn) / 8);
+    hipLaunchKernelGGL(pack_fin8_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, stream, w, c, nn, reinterpret_cast<half8*>(out));
+    hip_check(hipGetLastError(), "dcb_nsplit pack");
+}
 
 void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, int c, int ci, half_t* out, hipStream_t stream)
 {
@@ -123,6 +178,10 @@ void dcb_nsplit_pack_dc0(const half_t* w1, int c, int ci, half_t* out, hipStream
 {
     if (!dcb_nsplit_shape(c, ci)) throw std::invalid_argument("dcb_nsplit: unsupported block shape");
     const long long units = static_cast<long long>(dcb_nsplit_dc0_halves(c, ci) / 8);
+    if (ci % 128 != 0) {       // (8-wave kernel only, dcb_nsplit_shape)
+        dcb_nsplit_pack_fin(w1, c, ci, out, stream);
+        return;
+    }
     hipLaunchKernelGGL(dcb_nsplit_waves() == 8 ? pack_dc08_kernel : pack_dc0_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0,
                        stream, w1, c, ci, reinterpret_cast<half8*>(out));
     hip_check(hipGetLastError(), "dcb_nsplit pack");
@@ -161,7 +220,7 @@ bool dcb_nsplit_supported(int c, int cdc, int cffn)
 void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
 {
     if (!dcb_nsplit_shape(d.c, d.ci)) {
-        throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256) or (256, 128)");
+        throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256), (256, 128) or (384, 192)");
     }
     if (d.pixels <= 0) throw std::invalid_argument("dcb_nsplit: empty problem");
     if ((d.ldt % 8) || (d.ldx % 8) || (d.ldy % 8) || (d.wnext && d.ldt1 % 8)) {
@@ -170,6 +229,11 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     if (!d.t2 || !d.x || !d.wmain || !d.b3 || !d.b0 || !d.b2 || !d.y || (d.wnext && (!d.b1n || !d.t1n))) {
         throw std::invalid_argument("dcb_nsplit: missing operand");
     }
+    if (d.wfin != nullptr) {
+        if (d.wnext != nullptr) throw std::invalid_argument("dcb_nsplit: a block either hands dc.0 to the next block or closes the chain");
+        if (!dcb_nsplit_fin_supported(d.c, d.ci, d.nfin)) throw std::invalid_argument("dcb_nsplit: no kernel for this closing conv");
+        if (!d.bfin || !d.yfin || d.ldyfin % 8) throw std::invalid_argument("dcb_nsplit: closing conv needs bias, output and a leading dimension in units of 8");
+    }
     NsParams p{};
     p.t2 = d.t2; p.ldt = d.ldt; p.x = d.x; p.ldx = d.ldx;
     p.wmain = reinterpret_cast<const half8*>(d.wmain); p.wnext = reinterpret_cast<const half8*>(d.wnext);
@@ -177,14 +241,18 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     p.wsilu = wsilu_table_device();
     p.y = d.y; p.ldy = d.ldy; p.t1n = d.t1n; p.ldt1 = d.ldt1; p.M = d.pixels; p.shortcut = d.shortcut ? 1 : 0;
     p.timeline = g_ns_timeline;
+    if (d.wfin != nullptr) {      // the NEXT slot holds the chain's closing conv
+        p.wnext = reinterpret_cast<const half8*>(d.wfin); p.b1n = d.bfin; p.qf = d.qfin; p.t1n = d.yfin; p.ldt1 = d.ldyfin;
+    }
     // 64-pixel workgroups when they fill the chip (picture resolution / 8), 32 otherwise (/ 16: 255 workgroups at 1080p)
     // (768-wide blocks - the hierarchical models' prior fusion at / 16 - have LDS for 32 pixels only)
     // DCVC_NSPLIT_PX=32: 32-pixel workgroups everywhere (A/B: twice the tiles per workgroup, half the work per weight byte)
     static const bool narrow_all = [] { const char* e = getenv("DCVC_NSPLIT_PX"); return e != nullptr && atoi(e) == 32; }();
     const bool wide = d.pixels >= 64 * 200 && d.c < 768 && !narrow_all;
-    const bool next = d.wnext != nullptr;
     if (dcb_nsplit_waves() == 8) {
-        if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
+        const int next = d.wfin != nullptr ? d.nfin : d.wnext != nullptr ? 1 : 0;
+        if (d.c == 384 && d.ci == 192) nsplit8::run_384_192(p, wide, next, stream);
+        else if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
         else if (d.c == 768) nsplit8::run_768_768(p, wide, next, stream);
         else if (d.c == 512 && d.ci == 512) nsplit8::run_512_512(p, wide, next, stream);
         else if (d.c == 512) nsplit8::run_512_256(p, wide, next, stream);
@@ -192,6 +260,7 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
         else nsplit8::run_256_128(p, wide, next, stream);
         return;
     }
+    const bool next = d.wnext != nullptr;
     if (d.c == 384) run_384_384(p, wide, next, stream);
     else if (d.c == 768) run_768_768(p, wide, next, stream);
     else if (d.c == 512 && d.ci == 512) run_512_512(p, wide, next, stream);

@@ -4,9 +4,13 @@
 namespace dcvc {
 namespace nsplit8 {
 
-void run_256_256(const NsParams& p, bool wide, bool next, hipStream_t stream)
+// the variants with a chain-closing conv in the NEXT slot: dcb_nsplit8_256_256_fin.hip
+extern template void launch8<256, 256, 1, 192>(const NsParams&, hipStream_t);
+extern template void launch8<256, 256, 2, 192>(const NsParams&, hipStream_t);
+
+void run_256_256(const NsParams& p, bool wide, int next, hipStream_t stream)
 {
-    run_shape8<256, 256>(p, wide, next, stream);
+    run_shape8<256, 256, 192>(p, wide, next, stream);
 }
 
 }  // namespace nsplit8

@@ -4,7 +4,7 @@
 namespace dcvc {
 namespace nsplit8 {
 
-void run_384_384(const NsParams& p, bool wide, bool next, hipStream_t stream)
+void run_384_384(const NsParams& p, bool wide, int next, hipStream_t stream)
 {
     run_shape8<384, 384>(p, wide, next, stream);
 }

@@ -4,9 +4,15 @@
 namespace dcvc {
 namespace nsplit8 {
 
-void run_512_512(const NsParams& p, bool wide, bool next, hipStream_t stream)
+// the variants with a chain-closing conv in the NEXT slot: dcb_nsplit8_512_512_fin.hip
+extern template void launch8<512, 512, 1, 256>(const NsParams&, hipStream_t);
+extern template void launch8<512, 512, 2, 256>(const NsParams&, hipStream_t);
+extern template void launch8<512, 512, 1, 512>(const NsParams&, hipStream_t);
+extern template void launch8<512, 512, 2, 512>(const NsParams&, hipStream_t);
+
+void run_512_512(const NsParams& p, bool wide, int next, hipStream_t stream)
 {
-    run_shape8<512, 512>(p, wide, next, stream);
+    run_shape8<512, 512, 256, 512>(p, wide, next, stream);
 }
 
 }  // namespace nsplit8

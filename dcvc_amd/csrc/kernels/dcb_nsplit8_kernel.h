@@ -4,9 +4,13 @@
 //     y1 = W3 * t2 + b3' + x                          dc.3 (+ folded depthwise bias) + block input
 //     t  = chunk_add(WSiLU(W0 * y1 + b0))             ffn.0   (4x expansion, never materialised)
 //     y  = (W2 * t + b2 + y1 [+ x]) [* q] -> fp16 [* q2]     ffn.2 (+ block shortcut, + quant scales)
-//     [t1' = WSiLU(W1' * y + b1')]                    dc.0 of the NEXT block of a chain (optional)
+//     [t1' = WSiLU(W1' * y + b1')]                    dc.0 of the NEXT block of a chain (optional, NEXT = 1)
+//     [o   = (Wf * y + bf) [* qf] -> fp16]            or the 1x1 conv that CLOSES the chain (optional, NEXT = its width NN:
+//                                                     y_prior_fusion.conv.3, y_spatial_prior.conv.3, decoder.conv2 with its
+//                                                     quant scale, recon_head.head ...; round 6)
 //
-// Reference: DepthConvBlockProxy::forward, layers_proxy.cpp:71-101. Same contract, same arithmetic (contraction order,
+// Reference: DepthConvBlockProxy::forward, layers_proxy.cpp:71-101; the chain-closing convs dmci_proxy.cpp:145-199,
+// dmc_ld_proxy.cpp:420-593 (conv1x1_bias / conv1x1_bias_with_quant launches of their own there). Same contract, same arithmetic (contraction order,
 // bias-initialised accumulators, epilogue order, rounding points) as dcb_nsplit / conv_gemm: bit-identical
 // (tests/test_kernels_gpu.py) and equal to the oracle.
 //
@@ -57,10 +61,15 @@ constexpr int GB = NS8_GATHERS;          // table gathers in flight in the WSiLU
 #ifndef NS8_TRIPLE
 #define NS8_TRIPLE 1
 #endif
-template <int C, int CI, int PXT>
+template <int C, int CI, int PXT, int NEXT = 1>
 struct Lay {
-    static constexpr int BUF_A = 32 * PXT * CI * 2, BUF_B = 32 * PXT * C * 2;
-    static constexpr int CONSTS = (2 * C + 5 * CI) * 4 + 2 * C * 2;
+    // LDS rows are swizzled in groups of 16 chunks (256 bytes): an inner width of 192 (the LD model's (384, 192) prior
+    // fusion blocks) lives in rows of 256 channels, a third of them never read
+    static constexpr int CIP = (CI + 127) / 128 * 128;
+    static constexpr int BUF_A = 32 * PXT * CIP * 2, BUF_B = 32 * PXT * C * 2;
+    static constexpr int NB = NEXT > 1 ? NEXT : CI;                      // bias floats of the NEXT slot (dc.0: CI, closing conv: NN)
+    static constexpr int BIAS_FLOATS = 2 * C + 4 * CI + NB;
+    static constexpr int CONSTS = BIAS_FLOATS * 4 + 2 * C * 2;
     static constexpr bool FIT4 = 2 * BUF_A + BUF_B + 4 * TABLE_BYTES + CONSTS <= 160 * 1024 && (2 * BUF_A + BUF_B) % 16384 == 0;
     static constexpr bool FIT1 = 2 * BUF_A + BUF_B + 1 * TABLE_BYTES + CONSTS <= 160 * 1024 && (2 * BUF_A + BUF_B) % 4096 == 0;
     static constexpr bool TRIPLE = NS8_TRIPLE != 0 && (FIT4 || FIT1);
@@ -69,7 +78,7 @@ struct Lay {
     static constexpr int OFF_A2 = BUF_A + BUF_B;
     static constexpr int OFF_TABLE = TRIPLE ? 2 * BUF_A + BUF_B : align16k(BUF_A + BUF_B);
     static constexpr int OFF_BIAS = OFF_TABLE + RT * TABLE_BYTES;
-    static constexpr int OFF_Q = OFF_BIAS + (2 * C + 5 * CI) * 4;
+    static constexpr int OFF_Q = OFF_BIAS + BIAS_FLOATS * 4;
     static constexpr int BYTES = OFF_Q + 2 * C * 2;
     static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
@@ -81,36 +90,60 @@ struct Geo {
     static constexpr int QC = C / 128, QI = CI / 128;                  // tiles per SIMD pair of a C- / CI-wide layer
     static constexpr int HI_C = (QC + 1) / 2, LO_C = QC / 2;           // ... of which wave w < 4 / wave w + 4
     static constexpr int HI_I = (QI + 1) / 2, LO_I = QI / 2;
-    static constexpr int N0 = CI / 64;                                  // ffn.0 tiles per wave (4 CI / 32 / 8)
-    static constexpr int TP = 2, NP = N0 / TP;                          // passes of 2 tiles
-    static constexpr bool EVEN = HI_C == LO_C && HI_I == LO_I;
+    // CI a multiple of 128: dc.0's tiles by SIMD pair as the C-wide layers'; otherwise (CI = 192) by the rule of the closing
+    // convs below (waves 0 .. 3 one tile each, two of the waves 4 .. 7 one each)
+    static constexpr bool I_BY_PAIR = CI % 128 == 0;
+    // ffn.0: 4 CI / 32 tiles in pairs (a pair = 16 channels of t); the waves 0 .. 3 own P0_HI pairs each, 4 .. 7 P0_LO
+    // (equal but for CI = 192: 2 | 1)
+    static constexpr int PAIRS = CI / 16, P0_HI = (PAIRS + 7) / 8, P0_LO = (PAIRS - 4 * P0_HI) / 4;
+    static constexpr int TP = 2;                                        // passes of 2 tiles
+    static constexpr int n0(bool hiw) { return 2 * (hiw ? P0_HI : P0_LO); }      // ffn.0 tiles per wave
+    static constexpr int np(bool hiw) { return hiw ? P0_HI : P0_LO; }
+    static constexpr bool EVEN = HI_C == LO_C && HI_I == LO_I && I_BY_PAIR && P0_HI == P0_LO;
     static constexpr int nt_c(bool hiw) { return hiw ? HI_C : LO_C; }
-    static constexpr int nt_i(bool hiw) { return hiw ? HI_I : LO_I; }
+    static constexpr int nt_i(bool hiw) { return I_BY_PAIR ? (hiw ? HI_I : LO_I) : nt_f(CI, hiw); }
     static constexpr int f_dc3(bool hiw) { return nt_c(hiw) * KS_I; }
-    static constexpr int F_FFN0 = N0 * KS_C;
-    static constexpr int f_main(bool hiw) { return 2 * f_dc3(hiw) + F_FFN0; }
+    static constexpr int f_ffn0(bool hiw) { return n0(hiw) * KS_C; }
+    static constexpr int f_main(bool hiw) { return 2 * f_dc3(hiw) + f_ffn0(hiw); }
     static constexpr int f_dc0(bool hiw) { return nt_i(hiw) * KS_C; }
-    static_assert(C % 128 == 0 && CI % 128 == 0 && N0 % TP == 0, "channel counts in units of 4 SIMDs x 32");
+    // a chain-closing conv of width NN (C -> NN, NN / 32 tiles): the waves 0 .. 3 own nf_hi tiles each, of the waves 4 .. 7 the
+    // first act_lo own nf_lo each (NN = 192: 1 | 1, two active; NN = 128: 1 | 0). Wave w < 4: tiles [w nf_hi, ...), wave w >= 4:
+    // tiles [4 nf_hi + (w - 4) nf_lo, ...).
+    static constexpr int nf_hi(int nn) { return (nn / 32 + 7) / 8; }
+    static constexpr int nf_lo(int nn) { return nn / 32 - 4 * nf_hi(nn) <= 0 ? 0 : (nn / 32 - 4 * nf_hi(nn) + 3) / 4; }
+    static constexpr int act_lo(int nn) { return nf_lo(nn) == 0 ? 0 : (nn / 32 - 4 * nf_hi(nn)) / nf_lo(nn); }
+    static constexpr int nt_f(int nn, bool hiw) { return hiw ? nf_hi(nn) : nf_lo(nn); }
+    static constexpr bool fin_ok(int nn) { return nn % 32 == 0 && nn >= 128 && 4 * nf_hi(nn) + act_lo(nn) * nf_lo(nn) == nn / 32; }
+    // tiles / fragments of the NEXT slot (0: none, 1: dc.0 of the next block, NN > 1: closing conv of width NN)
+    static constexpr int nt_next(int next, bool hiw) { return next == 0 ? 0 : next == 1 ? nt_i(hiw) : nt_f(next, hiw); }
+    static constexpr int f_next(int next, bool hiw) { return nt_next(next, hiw) * KS_C; }
+    static constexpr bool even(int next) { return EVEN && (next <= 1 || (nf_hi(next) == nf_lo(next) && act_lo(next) == 4)); }
+    static_assert(C % 128 == 0 && CI % 64 == 0 && 4 * (P0_HI + P0_LO) == PAIRS && P0_LO >= 1, "channel counts the eight waves can share");
 };
 
-template <int C, int CI, int PXT, bool NEXT, bool HIW>
+template <int C, int CI, int PXT, int NEXT, bool HIW>
 __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
 {
     using G = Geo<C, CI>;
+    constexpr bool FIN = NEXT > 1;                                  // the NEXT slot is a chain-closing conv of width NEXT
+    static_assert(!FIN || G::fin_ok(NEXT), "closing conv: a width the eight waves can share");
+    static_assert(G::I_BY_PAIR || G::fin_ok(CI), "dc.0: an inner width the eight waves can share");
     constexpr int PX = 32 * PXT;
     constexpr int KS_C = G::KS_C, KS_I = G::KS_I;
-    constexpr int NT_C = G::nt_c(HIW), NT_I = G::nt_i(HIW), NP = G::NP, TP = G::TP;
-    constexpr int F_DC3 = G::f_dc3(HIW), F_FFN0 = G::F_FFN0, F_MAIN = G::f_main(HIW), F_DC0 = G::f_dc0(HIW);
-    constexpr int CH_C = C / 8, CH_I = CI / 8;                  // 16-byte chunks per row
-    constexpr int PITCH_C = C * 2, PITCH_I = CI * 2;
-    using L = Lay<C, CI, PXT>;
+    constexpr int NT_C = G::nt_c(HIW), NP = G::np(HIW), TP = G::TP;
+    constexpr int F_DC3 = G::f_dc3(HIW), F_FFN0 = G::f_ffn0(HIW), F_MAIN = G::f_main(HIW), F_DC0 = G::f_next(NEXT, HIW);
+    constexpr int NT_N = G::nt_next(NEXT, HIW);                     // this wave's 32-channel tiles of the NEXT slot
+    constexpr int CIP = Lay<C, CI, PXT, NEXT>::CIP;            // LDS row of the CI-wide tensors (padded to 16-chunk groups)
+    constexpr int CH_C = C / 8, CH_I = CIP / 8;                 // 16-byte chunks per LDS row
+    constexpr int PITCH_C = C * 2, PITCH_I = CIP * 2;
+    using L = Lay<C, CI, PXT, NEXT>;
     constexpr bool TRIPLE = L::TRIPLE;
     constexpr int RT = L::RT;
     constexpr int OFF_B = L::OFF_B, OFF_A2 = L::OFF_A2;
     constexpr int OFF_TABLE = L::OFF_TABLE;
-    constexpr int OFF_BIAS = L::OFF_BIAS;                           // fp32: b3 (C) | b0 (4 CI) | b2 (C) | b1n (CI)
-    constexpr int BIAS_FLOATS = 2 * C + 5 * CI;
-    constexpr int OFF_Q = L::OFF_Q;                                 // fp16: q | q2
+    constexpr int OFF_BIAS = L::OFF_BIAS;                           // fp32: b3 (C) | b0 (4 CI) | b2 (C) | b1n (CI; closing conv: NN)
+    constexpr int BIAS_FLOATS = L::BIAS_FLOATS;
+    constexpr int OFF_Q = L::OFF_Q;                                 // fp16: q | q2   (a closing conv's qf stays in memory: 16 bytes per 8 outputs)
     constexpr int TOTAL = F_MAIN + (NEXT ? F_DC0 : 0);
     static_assert((PX * CH_C) % NTHREADS == 0 && (PX * CH_I) % NTHREADS == 0, "tile rows must split evenly over the threads");
 
@@ -129,8 +162,13 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     // (HIW = the body of the waves with the larger share; where the shares are equal every wave runs it)
     const bool upper = wave >= 4;
     const int cb_c = 32 * (simd * G::QC + (upper ? G::HI_C : 0));
-    const int cb_i = 32 * (simd * G::QI + (upper ? G::HI_I : 0));
-    const int cb_0 = wave * (32 * G::N0);
+    const int cb_0 = HIW ? wave * (32 * G::n0(true)) : 4 * 32 * G::n0(true) + (wave - 4) * (32 * G::n0(false));
+    // the NEXT slot: first channel of this wave's share, and whether it has one (closing conv of 192 channels: waves 6, 7 idle)
+    constexpr bool BY_PAIR = !FIN && G::I_BY_PAIR;                   // dc.0 of a block whose inner width is a multiple of 128
+    constexpr int NN = FIN ? NEXT : CI;                              // width of the NEXT slot's output
+    const int cb_n = BY_PAIR ? 32 * (simd * G::QI + (upper ? G::HI_I : 0))
+                   : HIW ? 32 * wave * G::nf_hi(NN) : 32 * (4 * G::nf_hi(NN) + (wave - 4) * G::nf_lo(NN));
+    const bool nx_on = BY_PAIR || HIW || (wave - 4) < G::act_lo(NN);
     // stamps (wave 0, first tile): 0 entry | 1 constants + first t2 in LDS | 2 dc.3 done (barrier) | one per ffn.0 pass |
     // ffn.0 done (barrier) | ffn.2 MFMAs | ffn.2 done | dc.0 MFMAs | dc.0 done
     const long long rt0 = static_cast<long long>(__builtin_amdgcn_s_memrealtime());
@@ -172,11 +210,12 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     // ---- the wave's weight streams (dcb_nsplit.hip pack_*8): waves 0 .. 3 first (their share may be the larger one),
     // then 4 .. 7; fragment f of a wave at 1 KB f from the wave's base, lane-linear. Buffer loads: lane offset + 12-bit
     // immediate + one scalar offset per 4 KB, no VALU per fragment.
-    constexpr int FM_HI = G::f_main(true), FM_LO = G::f_main(false), FD_HI = G::f_dc0(true), FD_LO = G::f_dc0(false);
+    constexpr int FM_HI = G::f_main(true), FM_LO = G::f_main(false), FD_HI = G::f_next(NEXT, true), FD_LO = G::f_next(NEXT, false);
     unsigned wsm = static_cast<unsigned>((HIW ? wave * FM_HI : 4 * FM_HI + (wave - 4) * FM_LO) * 64 + lane) * 16u;
-    unsigned wsn = static_cast<unsigned>((HIW ? wave * FD_HI : 4 * FD_HI + (wave - 4) * FD_LO) * 64 + lane) * 16u;
+    // (a wave without a share of the closing conv still prefetches ring-deep behind ffn.2: from the stream's first bytes)
+    unsigned wsn = static_cast<unsigned>((HIW ? wave * FD_HI : nx_on ? 4 * FD_HI + (wave - 4) * FD_LO : 0) * 64 + lane) * 16u;
     const __amdgpu_buffer_rsrc_t rs_main = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8*>(p.wmain), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8*>(NEXT ? p.wnext : p.wmain), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8*>(NEXT != 0 ? p.wnext : p.wmain), 0, 0x7fffffff, 0x00020000);
     half8 ring[RING];
     auto issue = [&](auto f_tag) {
         constexpr int f = decltype(f_tag)::value;
@@ -199,7 +238,8 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         for (int i = 0; i < PX * CHN / NTHREADS; ++i) {
             const int pos = i * NTHREADS + tidv;
             const int r = pos / CHN, pc = pos % CHN;
-            const int lc = pc ^ (r & 15);
+            int lc = pc ^ (r & 15);
+            if constexpr (CHN * 8 != CI) lc = min(lc, CI / 8 - 1);      // a slot of the padding: any chunk of the row will do
             const int rr = min(r, last);
             lds_dma16(w, static_cast<unsigned>(rr * ld + lc * 8) * 2u, lds_base + lds_off + (i * NTHREADS + wave * 64) * 16);
         }
@@ -462,49 +502,69 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = hmul(o[e], q8[e]);
                     }
-                    if constexpr (NEXT) *slot = o;          // dc.0's operand
+                    if constexpr (NEXT != 0) *slot = o;     // the NEXT slot's operand
                     const int m = m0 + 32 * t + pxv;
                     if (m < p.M) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
                 }
     }
-    if constexpr (NEXT) __syncthreads();            // y complete in B
+    if constexpr (NEXT != 0) __syncthreads();       // y complete in B
     stamp();
 
-    // ================================================================ dc.0 of the next block: t1' = WSiLU(W1' y + b1')   (B -> memory)
-    if constexpr (NEXT && NT_I > 0) {
-        float16v acc[NT_I][PXT];
+    // ================================================================ the NEXT slot   (B -> memory)
+    //   NEXT = 1: dc.0 of the next block, t1' = WSiLU(W1' y + b1');  NEXT = NN: the chain's closing conv, o = (Wf y + bf) [* qf]
+    if constexpr (NEXT != 0 && NT_N > 0) {
+        if (nx_on) {
+            float16v acc[NT_N][PXT];
 #pragma unroll
-        for (int j = 0; j < NT_I; ++j)
+            for (int j = 0; j < NT_N; ++j)
 #pragma unroll
-            for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, cb_i + 32 * j);
-        contract(std::integral_constant<int, NT_I>{}, KsC{}, std::integral_constant<int, F_MAIN>{}, frag_b, acc);
-        // the ring is empty: the first fragments of the next tile go out now and arrive under the epilogue below
-        if (has_next) {
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, RING>([&](auto i) { issue(i); });
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stamp();
+                for (int t = 0; t < PXT; ++t) bias_tile(acc[j][t], lb1n, cb_n + 32 * j);
+            contract(std::integral_constant<int, NT_N>{}, KsC{}, std::integral_constant<int, F_MAIN>{}, frag_b, acc);
+            // the ring is empty: the first fragments of the next tile go out now and arrive under the epilogue below
+            if (has_next) {
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, RING>([&](auto i) { issue(i); });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stamp();
 #pragma unroll
-        for (int j = 0; j < NT_I; ++j)
+            for (int j = 0; j < NT_N; ++j)
 #pragma unroll
-            for (int t = 0; t < PXT; ++t)
+                for (int t = 0; t < PXT; ++t)
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    float v[8];
-                    runs_of(acc[j][t], pr, v);
-                    float4v c[8];
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float v[8];
+                        runs_of(acc[j][t], pr, v);
+                        half8 o;
+                        if constexpr (!FIN) {
+                            float4v c[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float4 r = wsilu_row_lds<RT, true>(v[e], tab);
-                        c[e] = float4v{r.x, r.y, r.z, r.w};
+                            for (int e = 0; e < 8; ++e) {
+                                const float4 r = wsilu_row_lds<RT, true>(v[e], tab);
+                                c[e] = float4v{r.x, r.y, r.z, r.w};
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], make_float4(c[e][0], c[e][1], c[e][2], c[e][3])));
+                        } else {
+                            if (p.qf != nullptr) {           // conv1x1_bias_with_quant: (acc) * q, one rounding
+                                const half8 q8 = *reinterpret_cast<const half8*>(p.qf + cb_n + 32 * j + 16 * pr + 8 * hiv);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = v[e] * static_cast<float>(q8[e]);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                        }
+                        const int m = m0 + 32 * t + pxv;
+                        if (m < p.M) store_line(p.t1n + static_cast<size_t>(m) * p.ldt1 + cb_n + 32 * j + 16 * pr + 8 * hiv, o);
                     }
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e] * wsilu_poly(v[e], make_float4(c[e][0], c[e][1], c[e][2], c[e][3])));
-                    const int m = m0 + 32 * t + pxv;
-                    if (m < p.M) store_line(p.t1n + static_cast<size_t>(m) * p.ldt1 + cb_i + 32 * j + 16 * pr + 8 * hiv, o);
-                }
+        } else {
+            if (has_next) {
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, RING>([&](auto i) { issue(i); });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stamp();
+        }
     } else {
         if (has_next) {
             __builtin_amdgcn_sched_barrier(0);
@@ -535,12 +595,12 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     }
 }
 
-template <int C, int CI, int PXT, bool NEXT>
+template <int C, int CI, int PXT, int NEXT>
 __global__ void __launch_bounds__(NTHREADS, 2)
 dcb_nsplit8_kernel(const NsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem8[];
-    if constexpr (Geo<C, CI>::EVEN) {
+    if constexpr (Geo<C, CI>::even(NEXT)) {
         block_body<C, CI, PXT, NEXT, true>(p, smem8);
     } else {
         // the waves of a SIMD pair own different numbers of tiles: two bodies, one barrier sequence
@@ -549,11 +609,11 @@ dcb_nsplit8_kernel(const NsParams p)
     }
 }
 
-template <int C, int CI, int PXT, bool NEXT>
+template <int C, int CI, int PXT, int NEXT>
 void launch8(const NsParams& p, hipStream_t stream)
 {
     auto kern = dcb_nsplit8_kernel<C, CI, PXT, NEXT>;
-    constexpr int smem = Lay<C, CI, PXT>::BYTES;
+    constexpr int smem = Lay<C, CI, PXT, NEXT>::BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
     constexpr int MAX_DEVICES = 64;
     static std::once_flag once[MAX_DEVICES];
@@ -577,7 +637,7 @@ void launch8(const NsParams& p, hipStream_t stream)
     const int tiles = (p.M + 32 * PXT - 1) / (32 * PXT);
     const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;
-    const int kflop = (NEXT ? 7 : 6) * CI;
+    const int kflop = 6 * CI + (NEXT == 1 ? CI : NEXT);      // 2 M C kflop = the launch's FLOPs (closing conv: + 2 M C NN)
     if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x50000000, 0.f}, &ev0, &ev1)) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, ev0, ev1, 0, p);
     } else {
@@ -586,22 +646,33 @@ void launch8(const NsParams& p, hipStream_t stream)
     hip_check(hipGetLastError(), "dcb_nsplit8 launch");
 }
 
-template <int C, int CI>
-void run_shape8(const NsParams& p, bool wide, bool next, hipStream_t stream)
+// `next`: 0 = nothing behind ffn.2, 1 = dc.0 of the next block, NN > 1 = the chain's closing conv of width NN (one of FINS...)
+template <int C, int CI, int PXT, int... FINS>
+void run_px8(const NsParams& p, int next, hipStream_t stream)
+{
+    if (next == 0) { launch8<C, CI, PXT, 0>(p, stream); return; }
+    if (next == 1) { launch8<C, CI, PXT, 1>(p, stream); return; }
+    const bool hit = ((next == FINS ? (launch8<C, CI, PXT, FINS>(p, stream), true) : false) || ... || false);
+    if (!hit) throw std::invalid_argument("dcb_nsplit8: no instantiation for a closing conv of width " + std::to_string(next));
+}
+
+template <int C, int CI, int... FINS>
+void run_shape8(const NsParams& p, bool wide, int next, hipStream_t stream)
 {
     if constexpr (C < 768) {
-        if (wide) { if (next) launch8<C, CI, 2, true>(p, stream); else launch8<C, CI, 2, false>(p, stream); return; }
+        if (wide) { run_px8<C, CI, 2, FINS...>(p, next, stream); return; }
     }
-    if (next) launch8<C, CI, 1, true>(p, stream); else launch8<C, CI, 1, false>(p, stream);
+    run_px8<C, CI, 1, FINS...>(p, next, stream);
 }
 
 // dcb_nsplit8_<shape>.hip
-void run_256_128(const NsParams& p, bool wide, bool next, hipStream_t stream);
-void run_256_256(const NsParams& p, bool wide, bool next, hipStream_t stream);
-void run_384_384(const NsParams& p, bool wide, bool next, hipStream_t stream);
-void run_512_256(const NsParams& p, bool wide, bool next, hipStream_t stream);
-void run_512_512(const NsParams& p, bool wide, bool next, hipStream_t stream);
-void run_768_768(const NsParams& p, bool wide, bool next, hipStream_t stream);
+void run_256_128(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_256_256(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_384_192(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_384_384(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_512_256(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_512_512(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_768_768(const NsParams& p, bool wide, int next, hipStream_t stream);
 
 }  // namespace nsplit8
 }  // namespace dcvc

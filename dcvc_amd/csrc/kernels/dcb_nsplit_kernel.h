@@ -125,6 +125,7 @@ struct NsParams {
     const half8* wnext;       // packed: [4 waves][F_DC0][64 lanes] or null
     const half_t* b3; const half_t* b0; const half_t* b2; const half_t* b1n;
     const half_t* q; const half_t* q2;
+    const half_t* qf;         // 8-wave kernel, closing conv in the NEXT slot (wnext / b1n / t1n / ldt1 are then ITS weights, bias, output): its quant scale or null
     const float4* wsilu;
     half_t* y; int ldy;
     half_t* t1n; int ldt1;

@@ -584,7 +584,9 @@ void launch_variant(const TailParams& p, bool dw, hipStream_t stream)
 
 bool shape_ok(int c, int cdc, int cffn)
 {
-    return (c == 128 || c == 256) && cdc % 64 == 0 && cdc >= 64 && cdc <= c / 2 && cffn % 64 == 0 && cffn >= 64;
+    // inner width <= 128: dc.0's four channel-tile waves, and W3 / W1 as whole matrices in the y1 area. The 128-wide blocks
+    // may be FULL width (cdc = 128: the intra model's hyper networks, round 6), the 256-wide ones are the half-width `dcb2` blocks
+    return (c == 128 || c == 256) && cdc % 64 == 0 && cdc >= 64 && cdc <= 128 && cffn % 64 == 0 && cffn >= 64;
 }
 
 half_t* g_dbg_t1 = nullptr;
@@ -617,7 +619,7 @@ bool dcb_tail_takes_dc0()
 void dcb_tail(const DcbTailDesc& d, hipStream_t stream)
 {
     if (!shape_ok(d.c, d.cdc, d.cffn) || d.H <= 0 || d.W <= 0) {
-        throw std::invalid_argument("dcb_tail: unsupported shape (C in {128, 256}, inner widths multiples of 64, C_dc <= C/2)");
+        throw std::invalid_argument("dcb_tail: unsupported shape (C in {128, 256}, inner widths multiples of 64, C_dc <= 128)");
     }
     if (d.ldt % 8 != 0 || d.ldx % 8 != 0 || d.ldy % 8 != 0) {
         throw std::invalid_argument("dcb_tail: leading dimensions must be multiples of 8");

@@ -82,6 +82,11 @@ struct DcbNsplitDesc {
     half_t* y = nullptr; int ldy = 0;
     int pixels = 0, c = 0, ci = 0;
     bool shortcut = false;
+    // round 6: instead of the next block's dc.0 the launch can run the 1x1 conv that CLOSES a chain (y_prior_fusion.conv.3,
+    // y_spatial_prior.conv.3, decoder.conv2, recon_head.head ...): yfin = (Wfin y + bfin) [* qfin] -> fp16, width nfin.
+    // wfin = dcb_nsplit_pack_fin's stream. Bit-identical to conv1x1(bias [, q]) on y.
+    const half_t* wfin = nullptr; const half_t* bfin = nullptr; const half_t* qfin = nullptr;
+    half_t* yfin = nullptr; int ldyfin = 0; int nfin = 0;
 };
 int dcb_nsplit_waves();                                      // 8 (round 4) or 4 (DCVC_NSPLIT_WAVES=4: round 3's kernel, A/B)
 bool dcb_nsplit_shape(int c, int ci);                         // a shape the kernel is instantiated for
@@ -90,6 +95,9 @@ size_t dcb_nsplit_main_halves(int c, int ci);
 size_t dcb_nsplit_dc0_halves(int c, int ci);
 void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, int c, int ci, half_t* out, hipStream_t stream);
 void dcb_nsplit_pack_dc0(const half_t* w1, int c, int ci, half_t* out, hipStream_t stream);
+bool dcb_nsplit_fin_supported(int c, int ci, int nn);        // a closing conv of width nn behind a (c, ci) block in one launch
+size_t dcb_nsplit_fin_halves(int c, int nn);
+void dcb_nsplit_pack_fin(const half_t* w /* [nn][c] */, int c, int nn, half_t* out, hipStream_t stream);
 void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream);
 void dcb_nsplit_timeline_buffer(long long* device_buffer);    // tuning aid: [workgroups][32] shader-clock stamps
 
@@ -136,7 +144,8 @@ void ffn_fused(const FfnFusedDesc& d, hipStream_t stream);
 // Everything of a half-width DepthConvBlock behind dc.0 in one launch (layers_proxy.cpp:79-98):
 //   t2 = depthwise3x3(t) (when dw != null; else t IS t2), y1 = W3 t2 + b3 + x, then the FFN
 //   out = W2 chunk_add(WSiLU(W0 y1 + b0)) + b2 + y1 [+ x when shortcut] [* q], rounded, [* q2].
-// c in {128, 256}, cdc <= c/2 and cffn multiples of 64. Bit-identical to the four-launch sequence.
+// c in {128, 256}, cdc <= 128 (half-width blocks, and the full-width 128-wide ones) and cffn multiples of 64. Bit-identical to the
+// four-launch sequence.
 // y may alias x; t must not alias y.
 struct DcbTailDesc {
     const half_t* w1 = nullptr;                 // dc.0 weights [cdc][c] + bias [cdc]: when given (with dw), dc.0 (1x1 +

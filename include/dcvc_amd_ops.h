@@ -87,6 +87,18 @@ int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void*
                     const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
                     const void* w1n, const void* b1n, void* t1n, int ldt1, void* y, int ldy,
                     int pixels, int c, int ci, int shortcut, void* stream);
+/* The same block as the LAST one of a chain, with the 1x1 conv that closes the chain inside the launch (round 6; the reference
+ * launches conv1x1_bias / conv1x1_bias_with_quant behind the block: y_prior_fusion.conv.3 dmci_proxy.cpp:172-176,
+ * y_spatial_prior.conv.3 dmci_proxy.cpp:196-199, decoder.conv2 dmc_ld_proxy.cpp:484-487, recon_head.head :499-503):
+ *   yfin = (Wfin * y + bfin) [* qfin] -> fp16,  Wfin [nfin][c].
+ * Returns an error for an (c, ci, nfin) the kernel has no variant of (dcvc_dcb_nsplit_fin_supported). Bit-identical to
+ * dcvc_dcb_nsplit followed by dcvc_conv1x1(bias [, q]). */
+int dcvc_dcb_nsplit_fin(const void* t2, int ldt, const void* x, int ldx, const void* w3, const void* b3,
+                        const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                        const void* wfin, const void* bfin, const void* qfin, void* yfin, int ldyfin, int nfin,
+                        void* y, int ldy, int pixels, int c, int ci, int shortcut, void* stream);
+int dcvc_dcb_nsplit_fin_supported(int c, int ci, int nfin);
+
 /* Handle form: pack w3 | w0 | w2 (and w1n, or NULL) once - the packed copies are a snapshot of the weights at pack time -,
  * launch any number of times, free (synchronises the device the handle was packed on, whichever is current). `stream` of
  * _pack and of _packed may differ: _packed orders its stream behind the pack launches (an event recorded by _pack).
@@ -103,7 +115,7 @@ int dcvc_dcb_nsplit_free(void* handle);
  * conv1x1_bias_wsilu_chunk_add, conv1x1_bias_shortcut[2][_with_quant]) in one launch for the
  * half-width blocks of the inter models: t = dc.0 output [H*W][ldt]; dw = [9][cdc] tap-major depthwise
  * weights (NULL: t already is the depthwise output); x = block-internal input (residual of dc.3, and
- * of ffn.2 when shortcut != 0); c in {128, 256}, cdc <= c/2, cffn: multiples of 64. Bit-identical to
+ * of ffn.2 when shortcut != 0); c in {128, 256}, cdc <= 128, cffn: multiples of 64. Bit-identical to
  * the four-launch sequence; y may alias x. With w1 / b1 (dc.0 weights [cdc][c] and bias) non-NULL, dc.0
  * (conv1x1_bias_wsilu on x) runs inside the launch too and t is not read - the whole block behind an
  * optional adaptor in one launch; y must then NOT alias x (patches read their neighbours' input). */

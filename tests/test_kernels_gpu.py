@@ -472,6 +472,12 @@ def test_ffn_fused_equals_two_launches(ops, P, C, CF, res2, quant, q2, inplace):
     (24, 40, 128, 64, 64, True, False, True, True, True),
     (136, 240, 256, 128, 128, True, False, False, True, True),
     (136, 240, 128, 64, 64, True, True, False, False, True),
+    # round 6: FULL-width 128-wide blocks (the intra model's hyper networks at / 16 .. / 64: five launches each until then)
+    (68, 120, 128, 128, 128, True, False, False, False, True),
+    (34, 60, 128, 128, 128, True, True, False, False, True),
+    (17, 30, 128, 128, 128, True, True, True, True, False),
+    (13, 37, 128, 128, 128, False, False, False, False, False),
+    (4, 4, 128, 128, 128, True, True, False, False, True),
 ])
 def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, quant, q2, dc0):
     """depthwise + dc.3 + ffn.0 + ffn.2 in one launch == dwconv3x3, conv1x1(residual),
@@ -558,6 +564,13 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     (256, 256, 30001, False, True, False, True, False),
     (256, 256, 27000, True, False, True, False, False),
     (256, 256, 129600, False, False, False, True, True),
+    # round 6: the low-delay model's prior fusion blocks: inner width 192 (LDS rows padded to 256 channels, ffn.0's tile pairs
+    # 2 | 1 over the waves of a SIMD, dc.0's six tiles on six of the eight waves)
+    (384, 192, 8160, False, False, False, True, True),
+    (384, 192, 8160, True, False, True, False, False),
+    (384, 192, 32640, False, True, False, True, False),
+    (384, 192, 12289, False, False, True, True, True),
+    (384, 192, 33, True, False, False, True, False),
 ])
 def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, nxt, inplace):
     """The same block through kernels/dcb_nsplit.hip (round 3: activations in LDS, every wave streams its quarter of
@@ -617,6 +630,77 @@ def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, n
         assert (t1[:, CI:] == 7.0).all()
     else:
         assert (t1 == 7.0).all()
+
+
+@pytest.mark.parametrize("C,CI,NN,P,shortcut,quant,qfin,inplace", [
+    (512, 512, 512, 8160, False, False, False, True),    # intra / HT-L: y_prior_fusion.conv.3, y_spatial_prior.conv.3 at / 16
+    (512, 512, 512, 32640, False, True, False, False),   # ... at 3840x2160 (64-pixel workgroups)
+    (512, 512, 256, 8160, False, False, False, True),    # HT-S: y_spatial_prior.conv.3 (256 of 512 channels out)
+    (512, 512, 256, 13001, True, False, True, False),    # ... ragged, 64-pixel workgroups, with a scale
+    (768, 768, 768, 8160, False, False, False, True),    # hierarchical models: y_prior_fusion.conv.3
+    (768, 768, 768, 777, True, False, True, False),
+    (256, 128, 128, 8160, False, False, False, True),    # LD: y_spatial_prior.conv.2 at / 16 (the upper waves have no tile)
+    (256, 128, 128, 32641, False, True, False, False),
+    (256, 128, 256, 32640, False, False, True, True),    # LD: decoder.conv2 with its quant scale at / 8
+    (256, 128, 256, 100, True, False, True, False),
+    (256, 128, 192, 32640, False, False, False, True),   # LD: recon_head.head (6 tiles: two of the upper waves idle)
+    (256, 128, 192, 12001, True, False, False, False),
+    (256, 128, 192, 20001, False, True, False, False),
+    (256, 128, 192, 70, False, False, True, False),
+    (256, 256, 192, 32640, False, False, False, True),   # hierarchical models: the 8 reconstruction heads
+    (256, 256, 192, 129600, False, False, False, True),  # ... at 3840x2160
+    (256, 256, 192, 513, True, False, True, False),
+    (256, 256, 192, 13513, False, True, True, False),
+    (384, 192, 384, 8160, False, False, False, True),    # LD: y_prior_fusion.conv.3 behind the (384, 192) blocks at / 16
+    (384, 192, 384, 32640, False, True, False, False),   # ... at 3840x2160
+    (384, 192, 384, 45, True, False, True, False),
+])
+def test_dcb_nsplit_closing_conv_equals_launch_sequence(ops, C, CI, NN, P, shortcut, quant, qfin, inplace):
+    """Round 6: the 1x1 conv that CLOSES a chain of blocks inside the last block's launch (the NEXT slot of the 8-wave kernel)
+    == the block's launch sequence followed by conv1x1(bias [, quant]) on its output, bit for bit; the block's own output
+    is still written."""
+    from gpu_util import call, ptr, stream
+    dev = "cuda"
+    if not ops.dcb_nsplit_fin_supported(C, CI, NN):
+        pytest.skip("no kernel variant (4-wave kernel selected)")
+    ldx = C + 64
+    xbuf = _rand((P, ldx), 1.0, 601).to(dev)
+    t2 = _rand((P, CI), 1.0, 602).to(dev)
+    w3 = (_rand((C, CI), 1.0, 603) / CI ** 0.5).half().to(dev)
+    b3 = _rand((C,), 0.3, 604).to(dev)
+    w0 = (_rand((4 * CI, C), 1.0, 605) / C ** 0.5).half().to(dev)
+    b0 = _rand((4 * CI,), 0.3, 606).to(dev)
+    w2 = (_rand((C, CI), 1.0, 607) / CI ** 0.5).half().to(dev)
+    b2 = _rand((C,), 0.3, 608).to(dev)
+    wf = (_rand((NN, C), 1.0, 609) / C ** 0.5).half().to(dev)
+    bf = _rand((NN,), 0.3, 610).to(dev)
+    q = (_rand((C,), 0.2, 611) + 1.0).half().to(dev) if quant else None
+    qf = (_rand((NN,), 0.2, 612) + 1.0).half().to(dev) if qfin else None
+    y1 = torch.zeros((P, C), dtype=torch.half, device=dev)
+    t = torch.zeros((P, CI), dtype=torch.half, device=dev)
+    want = torch.zeros((P, C), dtype=torch.half, device=dev)
+    want_f = torch.zeros((P, NN), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(t2), CI, ptr(w3), ptr(b3), ptr(xbuf), ldx, None, 0, None, None, ptr(y1), C, P, CI, C, 0, stream())
+    call(ops.conv1x1, ptr(y1), C, ptr(w0), ptr(b0), None, 0, None, 0, None, None, ptr(t), CI, P, C, 4 * CI, 3, stream())
+    call(ops.conv1x1, ptr(t), CI, ptr(w2), ptr(b2), ptr(y1), C, ptr(xbuf) if shortcut else None, ldx, ptr(q), None,
+         ptr(want), C, P, CI, C, 0, stream())
+    call(ops.conv1x1, ptr(want), C, ptr(wf), ptr(bf), None, 0, None, 0, ptr(qf), None, ptr(want_f), NN, P, C, NN, 0, stream())
+    torch.cuda.synchronize()
+    if inplace and not shortcut:
+        ybuf, ldy = xbuf.clone(), ldx
+        xin = ybuf
+    else:
+        ybuf, ldy = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev), C + 8
+        xin = xbuf
+    yf = torch.full((P, NN + 8), 7.0, dtype=torch.half, device=dev)
+    call(ops.dcb_nsplit_fin, ptr(t2), CI, ptr(xin), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), None,
+         ptr(wf), ptr(bf), ptr(qf), ptr(yf), NN + 8, NN, ptr(ybuf), ldy, P, C, CI, 1 if shortcut else 0, stream())
+    torch.cuda.synchronize()
+    bad = int((ybuf[:, :C] != want).sum())
+    assert bad == 0, "y: %d of %d outputs differ" % (bad, want.numel())
+    bad = int((yf[:, :NN] != want_f).sum())
+    assert bad == 0, "closing conv: %d of %d outputs differ" % (bad, want_f.numel())
+    assert (yf[:, NN:] == 7.0).all(), "channels beyond the closing conv's width untouched"
 
 
 def test_dcb_nsplit_reads_the_weights_of_the_call(ops):
