@@ -663,7 +663,7 @@ def pmc_traffic(kernel):
 
 
 KERNEL_NAMES = {0: "conv_gemm_kernel", 2: "dcb_tail_kernel", 3: "ffn_fused_kernel", 4: "dcb_nsplit_kernel",
-                5: "dcb_nsplit8_kernel"}
+                5: "dcb_nsplit8_kernel", 6: "dcb_pair8_kernel"}
 
 
 def roofline(work, n=len(QPS)):
@@ -717,18 +717,28 @@ def roofline(work, n=len(QPS)):
         if f in (4, 5):
             # one entry per shape of the N-split block kernel: <C, CI, pixels per workgroup> follows from (N, K, M): K = 7 CI
             # with the next block's dc.0 inside the launch, 6 CI without (dcb_nsplit_kernel.h launch())
-            inner = {k * ci: ci for ci in (128, 256, 384, 512, 768) for k in (6, 7)}
-            shapes = sorted({(int(a), int(b), inner[int(c)]) for a, b, c in zip(buf["M"][sel], buf["N"][sel], buf["K"][sel])})
+            var = buf["variant"].astype(np.int64)
+            if f == 5:       # the 8-wave kernel records its inner width and its NEXT slot (0, 1 = next dc.0, NN = closing conv)
+                ci_of, slot = var & 0xFFF, (var >> 12) & 0xFFF
+            else:
+                inner = {k * ci: ci for ci in (128, 256, 384, 512, 768) for k in (6, 7)}
+                ci_of = np.array([inner.get(int(c), 0) for c in buf["K"]], dtype=np.int64)
+                slot = (buf["K"] == 7 * ci_of).astype(np.int64)
+            width = np.where(slot == 1, ci_of, slot)                     # channels the NEXT slot writes
+            shapes = sorted({(int(a), int(b), int(c)) for a, b, c in zip(buf["M"][sel], buf["N"][sel], ci_of[sel])})
             for (m, c, ci) in shapes:
-                one = sel & (buf["M"] == m) & (buf["N"] == c) & ((buf["K"] == 6 * ci) | (buf["K"] == 7 * ci))
-                nxt = float((buf["K"][one] == 7 * ci).mean())            # share of the launches with the next dc.0
+                one = sel & (buf["M"] == m) & (buf["N"] == c) & (ci_of == ci)
+                nxt = float((slot[one] == 1).mean())                     # share of the launches with the next dc.0
+                fin = float((slot[one] > 1).mean())                      # ... with the chain's closing conv
+                wn = float(width[one].mean())                            # mean width of the NEXT slot's output
                 wide = m >= 64 * 200 and c < 768
-                # every operand once: t2 [M][CI], x [M][C] in, y [M][C] (and t1' [M][CI]) out, the block's weights
-                alg = 2 * m * (2 * c + ci + nxt * ci) + 2 * c * ci * (6 + nxt)
+                # every operand once: t2 [M][CI], x [M][C] in, y [M][C] (and the NEXT slot's output) out, the weights
+                alg = 2 * m * (2 * c + ci + wn) + 2 * c * (6 * ci + wn)
                 k = part(one, "%s<%d, %d, %d px>" % (name, c, ci, 64 if wide else 32), alg)
                 if k:
                     k["pixels"] = m
                     k["with_next_dc0"] = nxt
+                    k["with_closing_conv"] = fin
                     kernels.append(k)
             continue
         k = part(sel, name, None)

@@ -211,6 +211,31 @@ int dcvc_dcb_nsplit(const void* t2, int ldt, const void* x, int ldx, const void*
     });
 }
 
+int dcvc_dcb_pair_supported(int cin, int c, int ci)
+{
+    return dcvc::dcb_pair_supported(cin, c, ci) ? 1 : 0;
+}
+
+int dcvc_dcb_pair(const void* x, int ldx, const void* wa, const void* ba, const void* w1, const void* b1,
+                  void* y, int ldy, void* t1, int ldt1, int pixels, int cin, int c, int ci, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::kernels_init();
+        if (!dcvc::dcb_pair_supported(cin, c, ci)) throw std::invalid_argument("dcb_pair: no kernel variant for this shape");
+        if (!x || !wa || !ba || !w1 || !b1 || !y || !t1) throw std::invalid_argument("dcb_pair: missing operand");
+        if (x == y) throw std::invalid_argument("dcb_pair: the adaptor output must not alias its input");
+        hipStream_t st = S(stream);
+        const AsyncBuf pa(dcvc::dcb_pair_adaptor_halves(cin, c) * 2, st);
+        dcvc::dcb_pair_pack_adaptor(H(wa), cin, c, pa.half(), st);
+        const AsyncBuf p1(dcvc::dcb_nsplit_dc0_halves(c, ci) * 2, st);
+        dcvc::dcb_nsplit_pack_dc0(H(w1), c, ci, p1.half(), st);
+        dcvc::DcbPairDesc d;
+        d.x = H(x); d.ldx = ldx; d.wa = pa.half(); d.ba = H(ba); d.w1 = p1.half(); d.b1 = H(b1);
+        d.y = H(y); d.ldy = ldy; d.t1 = H(t1); d.ldt1 = ldt1; d.pixels = pixels; d.cin = cin; d.c = c; d.ci = ci;
+        dcvc::dcb_pair(d, st);
+    });
+}
+
 int dcvc_dcb_nsplit_fin_supported(int c, int ci, int nfin)
 {
     return dcvc::dcb_nsplit_fin_supported(c, ci, nfin) ? 1 : 0;

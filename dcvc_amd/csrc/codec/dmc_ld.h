@@ -55,9 +55,11 @@ private:
     void prepare(int height, int width);
     void select_qp(int qp, hipStream_t st);
     // sub-networks (operands are fixed views of the resident buffers, see prepare())
-    void run_fa_i(hipStream_t st);                    // FI -> memory
-    void run_fa_m(hipStream_t st);                    // [memory | feature_p] -> memory
-    void run_fe(hipStream_t st);                      // memory -> ctx
+    // feed_fe: the feature extractor runs RIGHT behind this chain (nothing in between touches the scratch planes): the
+    // chain's last launch also computes dc.0 of its first block, and run_fe is told so (dc0_done)
+    void run_fa_i(hipStream_t st, bool feed_fe = false);     // FI -> memory
+    void run_fa_m(hipStream_t st, bool feed_fe = false);     // [memory | feature_p] -> memory
+    void run_fe(hipStream_t st, bool dc0_done = false);      // memory -> ctx
     void run_tpe(hipStream_t st);                     // memory -> temporal params
     void run_encoder(hipStream_t st);                 // [x unshuffled | ctx] -> Y
     void run_hyper_encoder(hipStream_t st);           // Y -> z, z_hat

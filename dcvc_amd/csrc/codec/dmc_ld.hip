@@ -136,25 +136,27 @@ void DmcLdCodec::select_qp(int qp, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------ networks
-void DmcLdCodec::run_fa_i(hipStream_t st)
+void DmcLdCodec::run_fa_i(hipStream_t st, bool feed_fe)
 {
     const View t(m_T, kChM, kChM);
+    const bool feed = feed_fe && m_fa_i[3].feeds(m_fe[0]);
     run_dcb_chain(m_fa_i, 4, View(m_FI, kChSrc, kChSrc), t, View(m_CATM, kChM + kChD, kChM), m_g.H8, m_g.W8, m_s, st,
-                  nullptr, View(m_T2, kChM, kChM));
+                  nullptr, View(m_T2, kChM, kChM), nullptr, feed ? &m_fe[0] : nullptr);
 }
 
-void DmcLdCodec::run_fa_m(hipStream_t st)
+void DmcLdCodec::run_fa_m(hipStream_t st, bool feed_fe)
 {
     const View t(m_T, kChM, kChM);
+    const bool feed = feed_fe && m_fa_m[3].feeds(m_fe[0]);
     run_dcb_chain(m_fa_m, 4, View(m_CATM, kChM + kChD, kChM + kChD), t, View(m_CATM, kChM + kChD, kChM),
-                  m_g.H8, m_g.W8, m_s, st, nullptr, View(m_T2, kChM, kChM));
+                  m_g.H8, m_g.W8, m_s, st, nullptr, View(m_T2, kChM, kChM), nullptr, feed ? &m_fe[0] : nullptr);
 }
 
-void DmcLdCodec::run_fe(hipStream_t st)
+void DmcLdCodec::run_fe(hipStream_t st, bool dc0_done)
 {
     const View t(m_T, kChM, kChM);
     run_dcb_chain(m_fe, 5, View(m_CATM, kChM + kChD, kChM), t, View(m_CATD + kChD, kChD + kChM, kChM),
-                  m_g.H8, m_g.W8, m_s, st, nullptr, View(m_T2, kChM, kChM));
+                  m_g.H8, m_g.W8, m_s, st, nullptr, View(m_T2, kChM, kChM), nullptr, nullptr, dc0_done);
 }
 
 void DmcLdCodec::run_tpe(hipStream_t st)
@@ -247,8 +249,8 @@ void DmcLdCodec::add_ref_feature_from_frame(const half_t* frame, int height, int
     pad_unshuffle8(frame, height, width, 3, m_FI, m_g.H8, m_g.W8, st);
     if (apply_adaptor) {
         run_stage(kRef, st, [&] {
-            run_fa_i(st);
-            run_fe(st);
+            run_fa_i(st, true);
+            run_fe(st, m_fa_i[3].feeds(m_fe[0]));
             run_tpe(st);
         });
     }
@@ -295,11 +297,11 @@ int DmcLdCodec::compress(const half_t* x, int height, int width, int qp, bool re
         run_decoder(st);
         if (reset) {
             run_recon_head(nullptr, st);     // forward_reset, dmc_ld_proxy.cpp:297-305
-            run_fa_i(st);
+            run_fa_i(st, true);
         } else {
-            run_fa_m(st);
+            run_fa_m(st, true);
         }
-        run_fe(st);
+        run_fe(st, (reset ? m_fa_i[3] : m_fa_m[3]).feeds(m_fe[0]));      // its first dc.0 came with the adaptor chain's last launch
         run_tpe(st);
     });
     leave(user);

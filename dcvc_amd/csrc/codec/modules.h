@@ -105,6 +105,7 @@ struct DcbW {
     half_t* dw = nullptr;   // [9][cdc]
     half_t* packed_main = nullptr;   // dcb_nsplit.hip weight streams (full-width blocks of width 384 / 512)
     half_t* packed_dc0 = nullptr;
+    half_t* packed_adaptor = nullptr;   // dcb_pair.hip: adaptor + dc.0 in one launch, where the kernel has the shape
     int c = 0;              // block width (output channels)
     int cdc = 0;            // depthwise width (c or c/2)
     int cffn = 0;           // ffn inner width after chunk-add (c or c/2)
@@ -123,6 +124,8 @@ struct DcbW {
                  const half_t* q_fused = nullptr, const half_t* q_after = nullptr, View alt = View(),
                  const DcbW* next = nullptr, bool dc0_done = false, const FinCall* fin = nullptr) const;
     bool core_fused() const;                     // this block runs through dcb_nsplit
+    // this block on an H x W grid can run as ONE launch (dcb_tail with dc.0 inside) when its input is not its output
+    bool one_launch(int H, int W) const;
     bool nsplit() const { return packed_main != nullptr; }
     bool feeds(const DcbW& next) const;          // ... and can compute next's dc.0 on the way out
 };
@@ -179,8 +182,12 @@ struct DcbChain {
 };
 
 // the same launch sequence over a plain array of blocks (codecs that keep DcbW[n] members)
+// `after`: the first block of the chain that runs NEXT on this chain's output (it must satisfy blocks[n-1].feeds(*after)):
+// the last launch also computes its dc.0 into s.t1, and that chain is then run with first_dc0_done = true - nothing else
+// may touch s.t1 in between.
 void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, int W, const Scratch& s,
-                   hipStream_t st, const half_t* q_fused_last = nullptr, View tmp2 = View(), const FinCall* fin = nullptr);
+                   hipStream_t st, const half_t* q_fused_last = nullptr, View tmp2 = View(), const FinCall* fin = nullptr,
+                   const DcbW* after = nullptr, bool first_dc0_done = false);
 
 // dense k x k conv weight in tap-major layout
 struct ConvKW {

@@ -188,6 +188,10 @@ void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
         packed_dc0 = mem.alloc_half(dcb_nsplit_dc0_halves(c, cdc));
         dcb_nsplit_pack_main(dc3.w, ffn0.w, ffn2.w, c, cdc, packed_main, nullptr);
         dcb_nsplit_pack_dc0(dc0.w, c, cdc, packed_dc0, nullptr);
+        if (has_adaptor && adaptor.b != nullptr && dcb_pair_supported(adaptor.cin, c, cdc)) {
+            packed_adaptor = mem.alloc_half(dcb_pair_adaptor_halves(adaptor.cin, c));
+            dcb_pair_pack_adaptor(adaptor.w, adaptor.cin, c, packed_adaptor, nullptr);
+        }
         hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(pack)");
     }
 }
@@ -195,6 +199,12 @@ void DcbW::load(const ParamStore& ps, DeviceArena& mem, const std::string& p)
 bool DcbW::core_fused() const
 {
     return nsplit();
+}
+
+bool DcbW::one_launch(int H, int W) const
+{
+    return !nsplit() && !has_adaptor && dcb_tail_supported(H, W, c, cdc, cffn) && dcb_tail_takes_dc0() && ffn0.b != nullptr &&
+           ffn2.b != nullptr && dc3.b != nullptr && dc0.b != nullptr;
 }
 
 bool DcbW::feeds(const DcbW& next) const
@@ -227,10 +237,19 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         // the block output: without a spare buffer from the caller it goes to the third scratch plane, which that launch leaves alone
         if (alt.p == nullptr && tail && static_cast<size_t>(P) * c <= s.elems) alt = View(s.t3, c, c);
         const View a = (alt.p != nullptr && alt.p != y.p) ? View(alt.p, alt.ld, c) : y;
-        Conv1x1Desc d;
-        d.x = x.p; d.ldx = x.ld; d.w = adaptor.w; d.bias = adaptor.b;
-        d.y = a.p; d.ldy = a.ld; d.pixels = P; d.cin = adaptor.cin; d.cout = adaptor.cout;
-        conv1x1(d, st);
+        if (packed_adaptor != nullptr && nsplit() && a.p != x.p) {
+            // adaptor + dc.0 in ONE launch (kernels/dcb_pair8_kernel.h): the adaptor output stays in LDS as dc.0's operand
+            DcbPairDesc d;
+            d.x = x.p; d.ldx = x.ld; d.wa = packed_adaptor; d.ba = adaptor.b; d.w1 = packed_dc0; d.b1 = dc0.b;
+            d.y = a.p; d.ldy = a.ld; d.t1 = s.t1; d.ldt1 = cdc; d.pixels = P; d.cin = adaptor.cin; d.c = c; d.ci = cdc;
+            dcb_pair(d, st);
+            dc0_done = true;
+        } else {
+            Conv1x1Desc d;
+            d.x = x.p; d.ldx = x.ld; d.w = adaptor.w; d.bias = adaptor.b;
+            d.y = a.p; d.ldy = a.ld; d.pixels = P; d.cin = adaptor.cin; d.cout = adaptor.cout;
+            conv1x1(d, st);
+        }
         in = a;
     } else if (shortcut && x.p == y.p) {
         throw std::invalid_argument("DepthConvBlock with shortcut cannot run in place");
@@ -331,6 +350,12 @@ void Stride2W::forward(View x, View tmp, View y, int H, int W, const half_t* zer
     d.x = x.p; d.ldx = x.ld; d.w = w; d.bias = b; d.zeros = zeros;
     d.y = tmp.p; d.ldy = tmp.ld; d.in_h = H; d.in_w = W; d.cin = cin; d.cout = cout;
     d.ksize = 2; d.stride = 2; d.pad = 0;
+    // a caller without a buffer to spare passes tmp = y: the block would run in place, and the one-launch form (dc.0 on the
+    // halo of a patch) cannot. The third scratch plane is free in that form: the conv's output goes there instead
+    if (tmp.p == y.p && block.one_launch(H / 2, W / 2) && static_cast<size_t>(H / 2) * (W / 2) * cout <= s.elems) {
+        tmp = View(s.t3, cout, cout);
+        d.y = tmp.p; d.ldy = tmp.ld;
+    }
     conv_kxk(d, st);
     block.forward(tmp, y, H / 2, W / 2, s, st, shortcut);
 }
@@ -396,6 +421,9 @@ void UpsampleW::load(const ParamStore& ps, DeviceArena& mem, const std::string& 
 void UpsampleW::forward(View x, View tmp, View y, int H, int W, const Scratch& s, hipStream_t st,
                         half_t* up_tmp, const half_t* zeros, const DcbW* next) const
 {
+    if (tmp.p == y.p && block.one_launch(2 * H, 2 * W) && static_cast<size_t>(4) * H * W * up.cout <= s.elems) {
+        tmp = View(s.t3, up.cout, up.cout);      // (as Stride2W::forward: the one-launch block cannot run in place)
+    }
     up.forward(x, tmp, H, W, st, up_tmp, zeros);
     block.forward(tmp, y, 2 * H, 2 * W, s, st, shortcut, nullptr, nullptr, View(), next);
 }
@@ -411,14 +439,21 @@ void DcbChain::load(const ParamStore& ps, DeviceArena& mem, const std::string& p
 }
 
 void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, int W, const Scratch& s,
-                   hipStream_t st, const half_t* q_fused_last, View tmp2, const FinCall* fin)
+                   hipStream_t st, const half_t* q_fused_last, View tmp2, const FinCall* fin, const DcbW* after, bool first_dc0_done)
 {
+    if (after != nullptr && (fin != nullptr || !blocks[n - 1].feeds(*after))) {
+        throw std::invalid_argument("run_dcb_chain: the chain behind this one cannot take its dc.0 from the last launch");
+    }
+    auto next_of = [&](int i) -> const DcbW* {
+        if (i + 1 < n) return blocks[i].feeds(blocks[i + 1]) ? &blocks[i + 1] : nullptr;
+        return after;
+    };
     if (tmp2.p == nullptr) {
         View cur = x;
-        bool handed = false;            // the previous block left this block's dc.0 output in s.t1
+        bool handed = first_dc0_done;   // the previous block left this block's dc.0 output in s.t1
         for (int i = 0; i < n; ++i) {
             const View out = (i == n - 1) ? y : tmp;
-            const DcbW* next = (i + 1 < n && blocks[i].feeds(blocks[i + 1])) ? &blocks[i + 1] : nullptr;
+            const DcbW* next = next_of(i);
             blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr, nullptr, View(),
                               next, handed, i == n - 1 ? fin : nullptr);
             handed = next != nullptr;
@@ -430,7 +465,7 @@ void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, i
     // block runs in place (the one-launch block kernel needs input != output)
     const View a = tmp, b = tmp2;
     View cur = x;
-    bool handed = false;
+    bool handed = first_dc0_done;
     for (int i = 0; i < n; ++i) {
         View out = y;
         if (i != n - 1) {
@@ -439,7 +474,7 @@ void run_dcb_chain(const DcbW* blocks, int n, View x, View tmp, View y, int H, i
             out = (back % 2 == 1) ? (y_is_a ? b : a) : (y_is_a ? a : b);
         }
         const View spare = (out.p == a.p) ? b : a;              // for an adaptor: neither input nor output
-        const DcbW* next = (i + 1 < n && blocks[i].feeds(blocks[i + 1])) ? &blocks[i + 1] : nullptr;
+        const DcbW* next = next_of(i);
         blocks[i].forward(cur, out, H, W, s, st, false, i == n - 1 ? q_fused_last : nullptr, nullptr,
                           cur.p == spare.p ? View() : spare, next, handed, i == n - 1 ? fin : nullptr);
         handed = next != nullptr;

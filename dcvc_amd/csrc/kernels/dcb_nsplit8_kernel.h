@@ -638,7 +638,8 @@ void launch8(const NsParams& p, hipStream_t stream)
     const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;
     const int kflop = 6 * CI + (NEXT == 1 ? CI : NEXT);      // 2 M C kflop = the launch's FLOPs (closing conv: + 2 M C NN)
-    if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x50000000, 0.f}, &ev0, &ev1)) {
+    // (variant: family 5 | inner width | what the NEXT slot holds (0, 1 = dc.0, NN = a closing conv's width) << 12)
+    if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x50000000 | CI | (NEXT << 12), 0.f}, &ev0, &ev1)) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, ev0, ev1, 0, p);
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, p);

@@ -39,7 +39,8 @@ size_t gemm_profile_launches(GemmLaunchInfo* out, size_t cap);
 // Other contraction kernels (dcb_nsplit.hip, dcb_tail.hip, ffn_fused.hip) register their launches in the same list: when profiling
 // is on, reserves a record and hands out the two events hipExtLaunchKernelGGL stamps; false = off.
 // info.K is chosen such that 2 * M * N * K is the launch's FLOP count; variant bits 28..31 name the kernel
-// family: 0 conv_gemm, 2 dcb_tail, 3 ffn_fused, 4 dcb_nsplit, 5 dcb_nsplit8 (8 was round 2's dcb_core).
+// family: 0 conv_gemm, 2 dcb_tail, 3 ffn_fused, 4 dcb_nsplit, 5 dcb_nsplit8 (its variant also carries the inner width in bits
+// 0..11 and the NEXT slot - 0, 1 = next dc.0, NN = closing conv - in bits 12..23), 6 dcb_pair8 (8 was round 2's dcb_core).
 bool gemm_profile_slot(const GemmLaunchInfo& info, hipEvent_t* start, hipEvent_t* stop);
 // Tuning aid: when non-null, wave 0 of every workgroup of the following contraction launches
 // writes up to 16 shader-clock stamps (kernel entry, prologue issued, start of k-steps 0..7, main
@@ -100,6 +101,22 @@ size_t dcb_nsplit_fin_halves(int c, int nn);
 void dcb_nsplit_pack_fin(const half_t* w /* [nn][c] */, int c, int nn, half_t* out, hipStream_t stream);
 void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream);
 void dcb_nsplit_timeline_buffer(long long* device_buffer);    // tuning aid: [workgroups][32] shader-clock stamps
+
+// The two 1x1 convs in front of a block's depthwise conv in one launch (dcb_pair8_kernel.h, round 6):
+//   y = Wa x + ba (the block's adaptor, layers_proxy.cpp:73-77);  t1 = WSiLU(W1 y + b1) (dc.0, :79).
+// wa = dcb_pair_pack_adaptor's stream, w1 = the block's dcb_nsplit_pack_dc0 stream. Bit-identical to conv1x1 + conv1x1(wsilu).
+struct DcbPairDesc {
+    const half_t* x = nullptr; int ldx = 0;
+    const half_t* wa = nullptr; const half_t* ba = nullptr;
+    const half_t* w1 = nullptr; const half_t* b1 = nullptr;
+    half_t* y = nullptr; int ldy = 0;
+    half_t* t1 = nullptr; int ldt1 = 0;
+    int pixels = 0, cin = 0, c = 0, ci = 0;
+};
+bool dcb_pair_supported(int cin, int c, int ci);
+size_t dcb_pair_adaptor_halves(int cin, int c);
+void dcb_pair_pack_adaptor(const half_t* wa /* [c][cin] */, int cin, int c, half_t* out, hipStream_t stream);
+void dcb_pair(const DcbPairDesc& d, hipStream_t stream);
 
 struct ConvKxKDesc {
     const half_t* x = nullptr; int ldx = 0;     // [in_h][in_w][ldx]

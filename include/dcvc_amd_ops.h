@@ -99,6 +99,15 @@ int dcvc_dcb_nsplit_fin(const void* t2, int ldt, const void* x, int ldx, const v
                         void* y, int ldy, int pixels, int c, int ci, int shortcut, void* stream);
 int dcvc_dcb_nsplit_fin_supported(int c, int ci, int nfin);
 
+/* The two 1x1 convs in FRONT of a block's depthwise conv in one launch (round 6; the reference launches conv1x1_bias for the
+ * adaptor, layers_proxy.cpp:73-77, then conv1x1_bias_wsilu for dc.0, :79):
+ *   y = Wa * x + ba  (Wa [c][cin]);   t1 = WSiLU(W1 * y + b1)  (W1 [ci][c]).
+ * Returns an error for a (cin, c, ci) the kernel has no variant of (dcvc_dcb_pair_supported). y must not alias x.
+ * Bit-identical to dcvc_conv1x1(bias) followed by dcvc_conv1x1(bias, wsilu). */
+int dcvc_dcb_pair(const void* x, int ldx, const void* wa, const void* ba, const void* w1, const void* b1,
+                  void* y, int ldy, void* t1, int ldt1, int pixels, int cin, int c, int ci, void* stream);
+int dcvc_dcb_pair_supported(int cin, int c, int ci);
+
 /* Handle form: pack w3 | w0 | w2 (and w1n, or NULL) once - the packed copies are a snapshot of the weights at pack time -,
  * launch any number of times, free (synchronises the device the handle was packed on, whichever is current). `stream` of
  * _pack and of _packed may differ: _packed orders its stream behind the pack launches (an event recorded by _pack).

@@ -703,6 +703,54 @@ def test_dcb_nsplit_closing_conv_equals_launch_sequence(ops, C, CI, NN, P, short
     assert (yf[:, NN:] == 7.0).all(), "channels beyond the closing conv's width untouched"
 
 
+@pytest.mark.parametrize("CIN,C,CI,P", [
+    (448, 256, 128, 32640),    # LD: encoder.conv1.0 ([x unshuffled | ctx] -> 256) at / 8
+    (448, 256, 128, 77),
+    (512, 256, 128, 32640),    # LD: decoder.conv1.0, feature_adaptor_m.conv.0
+    (512, 256, 128, 8160),     # LD: y_spatial_prior.conv.0 at / 16 (32-pixel workgroups)
+    (512, 256, 128, 12801),    # ... ragged, 64-pixel workgroups
+    (192, 256, 128, 32640),    # LD: feature_adaptor_i.conv.0 (input rows padded to 256 channels in LDS)
+    (192, 256, 128, 100),
+    (128, 256, 256, 8160),     # intra: hyper_dec.conv.2
+    (512, 256, 256, 32640),    # hierarchical models: recon_head conv2 / conv .0
+    (512, 256, 256, 513),
+    (192, 384, 384, 32640),    # intra: enc.enc_1
+    (192, 384, 384, 12289),
+    (256, 512, 512, 8160),     # intra: y_prior_fusion.conv.0
+    (512, 512, 512, 8160),     # intra / hierarchical: y_spatial_prior_adaptor_k
+    (512, 512, 512, 32641),    # ... at 3840x2160
+    (192, 512, 512, 32640),    # HT-L: feature_adaptor_i.conv.0
+    (192, 512, 256, 32640),    # HT-S: feature_adaptor_i.conv.0
+    (192, 512, 256, 45),
+])
+def test_dcb_pair_equals_two_launches(ops, CIN, C, CI, P):
+    """Round 6: a block's adaptor and its dc.0 in ONE launch (kernels/dcb_pair8_kernel.h: the adaptor output stays in LDS as
+    dc.0's operand) == conv1x1(bias) followed by conv1x1(bias, wsilu), bit for bit, with channel-slice views either side."""
+    from gpu_util import call, ptr, stream
+    dev = "cuda"
+    if not ops.dcb_pair_supported(CIN, C, CI):
+        pytest.skip("no kernel variant (4-wave kernel selected)")
+    ldx = CIN + 64
+    xbuf = _rand((P, ldx), 1.0, 701).to(dev)
+    wa = (_rand((C, CIN), 1.0, 702) / CIN ** 0.5).half().to(dev)
+    ba = _rand((C,), 0.3, 703).to(dev)
+    w1 = (_rand((CI, C), 1.0, 704) / C ** 0.5).half().to(dev)
+    b1 = _rand((CI,), 0.3, 705).to(dev)
+    want_y = torch.zeros((P, C), dtype=torch.half, device=dev)
+    want_t = torch.zeros((P, CI), dtype=torch.half, device=dev)
+    call(ops.conv1x1, ptr(xbuf[:, 64:]), ldx, ptr(wa), ptr(ba), None, 0, None, 0, None, None, ptr(want_y), C, P, CIN, C, 0, stream())
+    call(ops.conv1x1, ptr(want_y), C, ptr(w1), ptr(b1), None, 0, None, 0, None, None, ptr(want_t), CI, P, C, CI, 1, stream())
+    y = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev)
+    t1 = torch.full((P, CI + 8), 7.0, dtype=torch.half, device=dev)
+    call(ops.dcb_pair, ptr(xbuf[:, 64:]), ldx, ptr(wa), ptr(ba), ptr(w1), ptr(b1), ptr(y), C + 8, ptr(t1), CI + 8, P, CIN, C, CI, stream())
+    torch.cuda.synchronize()
+    bad = int((y[:, :C] != want_y).sum())
+    assert bad == 0, "adaptor: %d of %d outputs differ" % (bad, want_y.numel())
+    bad = int((t1[:, :CI] != want_t).sum())
+    assert bad == 0, "dc.0: %d of %d outputs differ" % (bad, want_t.numel())
+    assert (y[:, C:] == 9.0).all() and (t1[:, CI:] == 7.0).all()
+
+
 def test_dcb_nsplit_reads_the_weights_of_the_call(ops):
     """dcvc_dcb_nsplit packs the weights it is GIVEN, on every call: rewriting them in place between two calls (same
     pointers - round 3's pointer-keyed cache returned the first call's copy, advisor finding) changes the result
