@@ -117,6 +117,8 @@ def parse_args():
     p.add_argument("--resolution", default=None, help="WxH of the synthetic pictures (default 1920x1080; 3840x2160 = configs[4], "
                                                       "the default of --sweep64)")
     p.add_argument("--no-uhd", action="store_true", help="skip the short 3840x2160 runs of the default line")
+    p.add_argument("--no-resolutions", action="store_true",
+                   help="skip the short 1280x720 / 832x480 runs of the default line (the reference's other tuned sizes)")
     p.add_argument("--min-seconds", type=float, default=2.0,
                    help="length of the `sustained` region behind the K timed steps (0 = none)")
     a = p.parse_args()
@@ -772,7 +774,8 @@ def common_fields(env, fps, elapsed, steps, scaling, metric, config):
             "dtype": "f16",
             "data": "synthetic (seeded low-pass noise + pan, 8-bit YUV420; seeded random weights of the reference architecture)",
             "config": config, "box": box_identity(env.device),
-            "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
+            "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                            "plugin_policy": getattr(sys.modules.get("inference_extensions_cuda"), "hw_queue_policy", None)}}
 
 
 def run_default(env, make_work):
@@ -893,6 +896,20 @@ def run_default(env, make_work):
             # BASELINE configs[4]: the 64-point rate sweep at 3840x2160, as a short run (1 I + 2 P pictures per rate point)
             uhd["sweep64"] = sweep64_block(env, "ld", 2160, 3840, 2)
             out["uhd"] = uhd
+        if not args.no_resolutions and (height, width) == (HEIGHT, WIDTH):
+            # the reference's other tuned picture sizes (README.md:202, cutlass/cutlass_kernel.h:229-249: per-shape tile tables for
+            # 1280x720, 832x480, 416x240 too); BASELINE.md holds an A100 row for 720p (encode / decode fps, reference-style)
+            res_block = {"reference_a100_720p": {"ld": [525.0, 501.2], "hts": [1098.4, 786.1], "htl": [648.2, 459.4],
+                                                 "source": "assets/complexity.png (b), BASELINE.md section 1: encode / decode fps"}}
+            for rh, rw in ((720, 1280), (480, 832)):
+                blk = {}
+                for kind in NAMES:
+                    o, w, nxt = fps_block_a(lambda pr, kind=kind, rh=rh, rw=rw: make_work(kind, rh, rw, frames=3, prioritised=pr),
+                                            24 if kind in ("hts", "htl") else 48, 6, with_pipeline=False)
+                    blk[kind] = o
+                    kept.append((o, w, nxt))
+                res_block["%dx%d" % (rw, rh)] = blk
+            out["resolutions"] = res_block
     # ---------------------------------------------------------------- phase A2: the two-stage pipelines (objects of their own,
     # streams at low / high priority) - behind every plain loop: what a plain loop on separate encoder / decoder objects reaches
     # depends on which streams have been created in the process before (profiles/r05_pipeline_order.txt: HIP multiplexes the
@@ -947,6 +964,8 @@ def compact_other(out):
         if isinstance(o, dict) and "value" in o and kind in NAMES:
             other["uhd_" + kind] = row(o)
     for res, block in (out.get("resolutions") or {}).items():
+        if not res[0].isdigit():
+            continue
         for kind, o in block.items():
             if isinstance(o, dict) and "value" in o:
                 other[res + "_" + kind] = row(o)

@@ -8,11 +8,44 @@ method names with the same argument meaning, implemented over the C ABI of libdc
 There is no fallback of any kind: a missing shared object or a failing call raises.
 """
 import ctypes
+import os
+import warnings
 
 import numpy as np
 import torch
 
-from dcvc_amd import _lib
+
+def _hw_queue_policy():
+    """ONE hardware queue per stream-priority level (ROCclr's GPU_MAX_HW_QUEUES; default 4) is what the codec objects were
+    measured with: every object brings a compute stream and a transfer stream, and with the runtime's default the throughput
+    of several objects in one process depended on the ORDER they were created in - up to 2x (profiles/r05_hw_queues.txt). The
+    variable is read when the HIP runtime starts, so:
+      * it is "1" already                       -> nothing to do ("set by the host")
+      * unset and the runtime has not started   -> set here ("set by the plug-in"); not with several ranks in the job (RCCL's
+                                                   stream would share the queue with the compute streams: never measured)
+      * anything else                           -> the runtime is up with its default (the reference harness imports this module
+                                                   lazily, behind its first CUDA call) or the host chose another value: WARN once,
+                                                   the drop-in must not silently run at half speed
+    Returns the policy string (also `hw_queue_policy` of this module; bench.py reports it)."""
+    val = os.environ.get("GPU_MAX_HW_QUEUES")
+    if val == "1":
+        return "GPU_MAX_HW_QUEUES=1 (set by the host)"
+    several_ranks = int(os.environ.get("WORLD_SIZE", "1") or "1") > 1
+    if val is None and not several_ranks and not torch.cuda.is_initialized():
+        os.environ["GPU_MAX_HW_QUEUES"] = "1"
+        return "GPU_MAX_HW_QUEUES=1 (set by the plug-in before the HIP runtime started)"
+    if several_ranks:
+        return "GPU_MAX_HW_QUEUES=%s (several ranks: left alone)" % val
+    warnings.warn("dcvc_amd: the HIP runtime %s; the codec objects were measured with GPU_MAX_HW_QUEUES=1 and can run up to 2x "
+                  "slower otherwise (INTEGRATION.md, section 1). Export GPU_MAX_HW_QUEUES=1 before the first CUDA / HIP call of "
+                  "the process." % ("is already up with its default of 4 hardware queues per priority level" if val is None
+                                    else "was given GPU_MAX_HW_QUEUES=%s" % val), RuntimeWarning, stacklevel=3)
+    return "GPU_MAX_HW_QUEUES=%s (NOT the measured setting)" % val
+
+
+hw_queue_policy = _hw_queue_policy()
+
+from dcvc_amd import _lib  # noqa: E402  (behind the policy: loading the library may start the runtime)
 
 _vp, _ci = ctypes.c_void_p, ctypes.c_int
 _F = dict(

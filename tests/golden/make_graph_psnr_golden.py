@@ -19,6 +19,12 @@ q 32 picture: 16.695 dB (skip_thres 0) against the graph's 16.382 dB, and 16.381
 mode off. `--oracle` adds the bit-exact oracle's own result for the skip-free setting (sha256 of its reconstruction and
 bit stream, ~ 160 s of 8 cores per picture): one more full-size digest per rate point for the product to equal.
 
+Round 6: the PSNR-against-the-source comparison is blunt with seeded random weights (both reconstructions sit at ~16 dB, so a
+0.02 dB gate passes any error below ~40 dB between the two reconstructions): a 128x128 crop of the graph's x_hat itself
+(fp16, the picture's centre) is stored per case in tests/golden/graph_xhat_crops.npz, and the test compares the product's
+reconstruction with it DIRECTLY (PSNR between the two crops against a floor measured on MI355X, `crop_psnr_floor`, kept
+when the file is regenerated).
+
 Usage: python tests/golden/make_graph_psnr_golden.py [--oracle]
 """
 import hashlib
@@ -40,6 +46,13 @@ CASES = [(1080, 1920, qp) for qp in (0, 16, 32, 48, 63)]   # (H, W, qp = picture
 SEED = 0
 SKIP_OFF = -60000.0
 OUT = os.path.join(ROOT, "tests", "golden", "graph_psnr_fullsize.json")
+CROPS = os.path.join(ROOT, "tests", "golden", "graph_xhat_crops.npz")
+CROP = 128                      # the crop is the CROP x CROP window at the picture's centre
+
+
+def crop_window(H, W):
+    y0, x0 = (H - CROP) // 2, (W - CROP) // 2
+    return y0, x0
 
 
 def psnr(a, b):
@@ -61,6 +74,7 @@ def main():
         with open(OUT) as f:
             out = json.load(f)
     with_oracle = "--oracle" in sys.argv
+    crops = {}
     with torch.no_grad():
         for H, W, qp in CASES:
             x = picture(H, W, index=qp)                             # fp16 [H, W, 3], what the codecs are fed
@@ -75,12 +89,15 @@ def main():
             xh = x_hat[0].permute(1, 2, 0).numpy().clip(-0.5, 0.5)[:H, :W]
             src = x.astype(np.float32)
             name = "dmci_%dx%d_q%d_noskip" % (W, H, qp)
-            keep = {k: v for k, v in out.get(name, {}).items() if k.startswith("oracle_")}
+            keep = {k: v for k, v in out.get(name, {}).items() if k.startswith("oracle_") or k == "crop_psnr_floor"}
+            y0, x0 = crop_window(H, W)
+            crops[name] = xh[y0:y0 + CROP, x0:x0 + CROP].astype(np.float16)
             out[name] = {
                 "height": H, "width": W, "qp": qp, "index": qp, "input": hashlib.sha256(x.tobytes()).hexdigest(),
                 "graph_padding": [pb, pr],
                 "psnr": psnr(xh, src), "psnr_planes": [psnr(xh[..., c], src[..., c]) for c in range(3)],
                 "x_hat_mean": float(xh.mean()), "x_hat_std": float(xh.std()), "graph_seconds": round(dt, 1),
+                "crop": [y0, x0, CROP], "crop_sha256": hashlib.sha256(crops[name].tobytes()).hexdigest(),
             }
             out[name].update(keep)
             if with_oracle and "oracle_x_hat" not in out[name]:
@@ -100,7 +117,8 @@ def main():
                 json.dump(out, f, indent=1, sort_keys=True)
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print("wrote", OUT)
+    np.savez_compressed(CROPS, **crops)
+    print("wrote", OUT, CROPS)
 
 
 if __name__ == "__main__":

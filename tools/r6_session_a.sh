@@ -20,7 +20,7 @@ for w in intra ld hts htl; do
   head -14 $O/${w}_per_picture.txt
 done
 cd $R
-timeout 900 python bench.py --no-cpu-baseline --no-uhd > $O/bench_line.json 2> $O/bench.err
+timeout 900 python bench.py --no-cpu-baseline --no-uhd --no-resolutions > $O/bench_line.json 2> $O/bench.err
 python - <<PY
 import json
 d = json.load(open("$O/bench_line.json"))
