@@ -48,7 +48,12 @@ constexpr int NTHREADS = 512;
 #ifndef NS8_RING
 #define NS8_RING 8
 #endif
-constexpr int RING = NS8_RING;           // weight fragments in flight per wave (4 registers each)
+constexpr int RING = NS8_RING;           // weight fragments in flight per wave (4 registers each): 64-pixel workgroups
+// 32-pixel workgroups (PXT = 1: the prior networks at picture resolution / 16) have the registers for a deeper ring, and need it:
+// a fragment feeds ONE MFMA there, the weight stream per workgroup is the bound (round 6: profiles/r06_ring_px32.txt)
+#ifndef NS8_RING1
+#define NS8_RING1 8
+#endif
 #ifndef NS8_GATHERS
 #define NS8_GATHERS 8
 #endif
@@ -125,6 +130,7 @@ template <int C, int CI, int PXT, int NEXT, bool HIW>
 __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
 {
     using G = Geo<C, CI>;
+    constexpr int RING = PXT == 1 ? NS8_RING1 : NS8_RING;           // (shadows the namespace's value: every use below is the body's)
     constexpr bool FIN = NEXT > 1;                                  // the NEXT slot is a chain-closing conv of width NEXT
     static_assert(!FIN || G::fin_ok(NEXT), "closing conv: a width the eight waves can share");
     static_assert(G::I_BY_PAIR || G::fin_ok(CI), "dc.0: an inner width the eight waves can share");
