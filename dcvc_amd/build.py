@@ -164,6 +164,12 @@ def _build_locked(force, verbose, srcs, manifest, digest):
         have = open(stamp).read() if os.path.exists(stamp) else ""
         if force or not os.path.exists(o) or have != want:
             jobs.append((s, o, stamp, want))
+    # objects (and stamps) of sources that no longer exist: not linked, but they would travel with every snapshot of the tree
+    keep = set(objs) | {o + ".stamp" for o in objs}
+    for name in os.listdir(OBJ):
+        path = os.path.join(OBJ, name)
+        if path not in keep and (name.endswith(".o") or name.endswith(".stamp")):
+            os.remove(path)
     if jobs:
         def run(job):
             _compile(job[0], job[1], verbose)

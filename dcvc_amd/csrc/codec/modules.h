@@ -94,6 +94,7 @@ struct FinCall {
     const FinW* w = nullptr;
     const half_t* q = nullptr;       // conv1x1_bias_with_quant's scale or null
     half_t* y = nullptr; int ldy = 0;
+    bool keep_block_output = false;  // false: where the conv runs inside the block launch, the block's own output is not stored
     FinCall() = default;
     FinCall(const FinW& w_, half_t* y_, int ldy_, const half_t* q_ = nullptr) : w(&w_), q(q_), y(y_), ldy(ldy_) {}
 };

@@ -287,6 +287,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         if (fin_inside) {
             d.wfin = fin->w->packed; d.bfin = fin->w->conv.b; d.qfin = fin->q; d.yfin = fin->y; d.ldyfin = fin->ldy;
             d.nfin = fin->w->conv.cout;
+            if (!fin->keep_block_output && !shortcut) d.y = nullptr;      // (with the block shortcut y may alias x: keep it simple)
         }
         dcb_nsplit(d, st);
         if (fin != nullptr && !fin_inside) run_fin(*fin, y, P, st);

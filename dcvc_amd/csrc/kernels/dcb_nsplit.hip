@@ -1,5 +1,4 @@
-// Host side of the N-split DepthConvBlock kernel (dcb_nsplit_kernel.h): weight packing, shape dispatch.
-#include "dcb_nsplit_kernel.h"
+// Host side of the N-split DepthConvBlock kernel (dcb_nsplit8_kernel.h): weight packing, shape dispatch.
 #include "dcb_nsplit8_kernel.h"
 
 namespace dcvc {
@@ -11,42 +10,7 @@ namespace {
 // ------------------------------------------------------------------------------------ weight packing
 // [waves][fragments][64 lanes][8 halves]: fragment = the MFMA "A" operand of one (32-channel tile, 16-deep k-slice):
 // lane l holds row (l & 31), k = 8 (l >> 5) .. + 7. Order inside a wave's stream = the order the kernel consumes.
-__global__ void pack_main_kernel(const half_t* w3, const half_t* w0, const half_t* w2, int C, int CI, half8* out)
-{
-    const int KS_C = C / 16, KS_I = CI / 16, MT_C = C / 128, TP = CI >= 256 ? 4 : 2, NP = CI / (32 * TP);
-    const int F_DC3 = MT_C * KS_I, F_FFN0 = NP * TP * KS_C, F_MAIN = 2 * F_DC3 + F_FFN0;
-    const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (u >= 4LL * F_MAIN * 64) return;
-    const int lane = static_cast<int>(u & 63);
-    const int f = static_cast<int>((u >> 6) % F_MAIN);
-    const int wave = static_cast<int>((u >> 6) / F_MAIN);
-    const half_t* w;
-    int n0, ks, K;
-    if (f < F_DC3) {                                  // dc.3 [C][CI]
-        ks = f / MT_C; n0 = 32 * (wave * MT_C + f % MT_C); w = w3; K = CI;
-    } else if (f < F_DC3 + F_FFN0) {                  // ffn.0 [4 CI][C]: the wave's CI channels in passes of TP tiles
-        const int g = f - F_DC3, pass = g / (TP * KS_C), r = g % (TP * KS_C);
-        ks = r / TP; n0 = wave * CI + pass * 32 * TP + 32 * (r % TP); w = w0; K = C;
-    } else {                                          // ffn.2 [C][CI]
-        const int g = f - F_DC3 - F_FFN0;
-        ks = g / MT_C; n0 = 32 * (wave * MT_C + g % MT_C); w = w2; K = CI;
-    }
-    out[u] = *reinterpret_cast<const half8*>(w + static_cast<size_t>(n0 + (lane & 31)) * K + 16 * ks + 8 * (lane >> 5));
-}
-
-__global__ void pack_dc0_kernel(const half_t* w1, int C, int CI, half8* out)       // dc.0 [CI][C]
-{
-    const int KS_C = C / 16, MT_I = CI / 128, F = MT_I * KS_C;
-    const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (u >= 4LL * F * 64) return;
-    const int lane = static_cast<int>(u & 63);
-    const int f = static_cast<int>((u >> 6) % F);
-    const int wave = static_cast<int>((u >> 6) / F);
-    const int ks = f / MT_I, n0 = 32 * (wave * MT_I + f % MT_I);
-    out[u] = *reinterpret_cast<const half8*>(w1 + static_cast<size_t>(n0 + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5));
-}
-
-// ---- the 8-wave kernel's streams (dcb_nsplit8_kernel.h): waves 0 .. 3, then 4 .. 7; waves w and w + 4 share the tiles
+// the kernel's streams (dcb_nsplit8_kernel.h): waves 0 .. 3, then 4 .. 7; waves w and w + 4 share the tiles
 // [simd QC, (simd + 1) QC) of a C-wide layer (w the first HI, w + 4 the remaining LO); ffn.0: N0 tiles per wave in passes of 2
 __global__ void pack_main8_kernel(const half_t* w3, const half_t* w0, const half_t* w2, int C, int CI, half8* out)
 {
@@ -116,20 +80,18 @@ long long* g_ns_timeline = nullptr;
 
 }  // namespace
 
-int dcb_nsplit_waves();
-
 bool dcb_nsplit_shape(int c, int ci)
 {
     return (c == 384 && ci == 384) || (c == 512 && ci == 512) || (c == 768 && ci == 768) || (c == 256 && ci == 256) ||
            (c == 512 && ci == 256) || (c == 256 && ci == 128) ||
-           (c == 384 && ci == 192 && dcb_nsplit_waves() == 8);       // round 6: the LD model's prior fusion blocks (8-wave kernel only)
+           (c == 384 && ci == 192);       // round 6: the LD model's prior fusion blocks
 }
 
 // widths of a chain-closing conv the 8-wave kernel of a block shape is instantiated for (dcb_nsplit8_<shape>_fin.hip)
 bool dcb_nsplit_fin_supported(int c, int ci, int nn)
 {
     static const bool off = [] { const char* e = getenv("DCVC_NSPLIT_FIN"); return e != nullptr && atoi(e) == 0; }();   // A/B: the closing convs as launches of their own
-    if (off || dcb_nsplit_waves() != 8 || !dcb_nsplit_shape(c, ci)) return false;
+    if (off || !dcb_nsplit_shape(c, ci)) return false;
     if (c == 256 && ci == 128) return nn == 128 || nn == 192 || nn == 256;
     if (c == 256 && ci == 256) return nn == 192;
     if (c == 512 && ci == 512) return nn == 256 || nn == 512;
@@ -169,7 +131,7 @@ void dcb_nsplit_pack_main(const half_t* w3, const half_t* w0, const half_t* w2, 
 {
     if (!dcb_nsplit_shape(c, ci)) throw std::invalid_argument("dcb_nsplit: unsupported block shape");
     const long long units = static_cast<long long>(dcb_nsplit_main_halves(c, ci) / 8);
-    hipLaunchKernelGGL(dcb_nsplit_waves() == 8 ? pack_main8_kernel : pack_main_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(pack_main8_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0,
                        stream, w3, w0, w2, c, ci, reinterpret_cast<half8*>(out));
     hip_check(hipGetLastError(), "dcb_nsplit pack");
 }
@@ -178,28 +140,18 @@ void dcb_nsplit_pack_dc0(const half_t* w1, int c, int ci, half_t* out, hipStream
 {
     if (!dcb_nsplit_shape(c, ci)) throw std::invalid_argument("dcb_nsplit: unsupported block shape");
     const long long units = static_cast<long long>(dcb_nsplit_dc0_halves(c, ci) / 8);
-    if (ci % 128 != 0) {       // (8-wave kernel only, dcb_nsplit_shape)
+    if (ci % 128 != 0) {
         dcb_nsplit_pack_fin(w1, c, ci, out, stream);
         return;
     }
-    hipLaunchKernelGGL(dcb_nsplit_waves() == 8 ? pack_dc08_kernel : pack_dc0_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(pack_dc08_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0,
                        stream, w1, c, ci, reinterpret_cast<half8*>(out));
     hip_check(hipGetLastError(), "dcb_nsplit pack");
 }
 
-#ifndef NS_WAVES_DEFAULT
-#define NS_WAVES_DEFAULT 8
-#endif
 int dcb_nsplit_waves()
 {
-    // waves per workgroup of the block kernel: 8 = dcb_nsplit8_kernel.h (round 4), 4 = dcb_nsplit_kernel.h (round 3; the A/B
-    // partner, DCVC_NSPLIT_WAVES=4). Read once: the packed weight streams of a process are laid out for one of the two.
-    static const int waves = [] {
-        const char* e = getenv("DCVC_NSPLIT_WAVES");
-        const int w = e != nullptr ? atoi(e) : NS_WAVES_DEFAULT;
-        return w == 4 ? 4 : 8;
-    }();
-    return waves;
+    return 8;       // (round 3's 4-wave form, DCVC_NSPLIT_WAVES=4, was the A/B partner through rounds 4 and 5: retired in round 6)
 }
 
 int dcb_nsplit_mode()
@@ -226,7 +178,7 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     if ((d.ldt % 8) || (d.ldx % 8) || (d.ldy % 8) || (d.wnext && d.ldt1 % 8)) {
         throw std::invalid_argument("dcb_nsplit: leading dimensions must be multiples of 8 channels");
     }
-    if (!d.t2 || !d.x || !d.wmain || !d.b3 || !d.b0 || !d.b2 || !d.y || (d.wnext && (!d.b1n || !d.t1n))) {
+    if (!d.t2 || !d.x || !d.wmain || !d.b3 || !d.b0 || !d.b2 || (!d.y && !d.wfin) || (d.wnext && (!d.b1n || !d.t1n))) {
         throw std::invalid_argument("dcb_nsplit: missing operand");
     }
     if (d.wfin != nullptr) {
@@ -249,24 +201,14 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     // DCVC_NSPLIT_PX=32: 32-pixel workgroups everywhere (A/B: twice the tiles per workgroup, half the work per weight byte)
     static const bool narrow_all = [] { const char* e = getenv("DCVC_NSPLIT_PX"); return e != nullptr && atoi(e) == 32; }();
     const bool wide = d.pixels >= 64 * 200 && d.c < 768 && !narrow_all;
-    if (dcb_nsplit_waves() == 8) {
-        const int next = d.wfin != nullptr ? d.nfin : d.wnext != nullptr ? 1 : 0;
-        if (d.c == 384 && d.ci == 192) nsplit8::run_384_192(p, wide, next, stream);
-        else if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
-        else if (d.c == 768) nsplit8::run_768_768(p, wide, next, stream);
-        else if (d.c == 512 && d.ci == 512) nsplit8::run_512_512(p, wide, next, stream);
-        else if (d.c == 512) nsplit8::run_512_256(p, wide, next, stream);
-        else if (d.ci == 256) nsplit8::run_256_256(p, wide, next, stream);
-        else nsplit8::run_256_128(p, wide, next, stream);
-        return;
-    }
-    const bool next = d.wnext != nullptr;
-    if (d.c == 384) run_384_384(p, wide, next, stream);
-    else if (d.c == 768) run_768_768(p, wide, next, stream);
-    else if (d.c == 512 && d.ci == 512) run_512_512(p, wide, next, stream);
-    else if (d.c == 512) run_512_256(p, wide, next, stream);
-    else if (d.ci == 256) run_256_256(p, wide, next, stream);
-    else run_256_128(p, wide, next, stream);
+    const int next = d.wfin != nullptr ? d.nfin : d.wnext != nullptr ? 1 : 0;
+    if (d.c == 384 && d.ci == 192) nsplit8::run_384_192(p, wide, next, stream);
+    else if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
+    else if (d.c == 768) nsplit8::run_768_768(p, wide, next, stream);
+    else if (d.c == 512 && d.ci == 512) nsplit8::run_512_512(p, wide, next, stream);
+    else if (d.c == 512) nsplit8::run_512_256(p, wide, next, stream);
+    else if (d.ci == 256) nsplit8::run_256_256(p, wide, next, stream);
+    else nsplit8::run_256_128(p, wide, next, stream);
 }
 
 }  // namespace dcvc

@@ -1,5 +1,5 @@
 // dcb_nsplit8_kernel.h instantiated for the (384, 192) blocks - the low-delay model's prior fusion at picture resolution / 16
-// (round 6; one translation unit per block shape: see dcb_nsplit_kernel.h)
+// (round 6; one translation unit per block shape)
 #include "dcb_nsplit8_kernel.h"
 
 namespace dcvc {

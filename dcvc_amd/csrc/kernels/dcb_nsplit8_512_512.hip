@@ -1,4 +1,4 @@
-// dcb_nsplit8_kernel.h instantiated for the (512, 512) blocks (one translation unit per block shape: see dcb_nsplit_kernel.h)
+// dcb_nsplit8_kernel.h instantiated for the (512, 512) blocks (one translation unit per block shape: the fully unrolled kernels take minutes to compile, the build runs the units in parallel)
 #include "dcb_nsplit8_kernel.h"
 
 namespace dcvc {

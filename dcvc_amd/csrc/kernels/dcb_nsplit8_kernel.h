@@ -1,5 +1,6 @@
-// dcb_nsplit8_kernel.h - the N-split DepthConvBlock kernel (dcb_nsplit_kernel.h) with EIGHT waves per workgroup:
-// two per SIMD, 256 registers each, every wave owning an EIGHTH of a layer's output channels.
+// dcb_nsplit8_kernel.h - the N-split DepthConvBlock kernel: a DepthConvBlock behind its depthwise conv in ONE launch,
+// activations in LDS, EIGHT waves per workgroup - two per SIMD, 256 registers each, every wave owning an EIGHTH of a layer's
+// output channels and streaming ITS weights from L2 (round 3 introduced the N-split form with four waves; round 4 this one).
 //
 //     y1 = W3 * t2 + b3' + x                          dc.3 (+ folded depthwise bias) + block input
 //     t  = chunk_add(WSiLU(W0 * y1 + b0))             ffn.0   (4x expansion, never materialised)
@@ -28,10 +29,10 @@
 //     buffer_load; the workgroup as a whole still reads each weight byte once per 64 pixels;
 //   * no software pipelining inside a wave: a pass is [MFMAs] [its WSiLU + chunk-add epilogue], the partner wave fills
 //     the matrix pipe meanwhile. One accumulator set: 256 registers suffice.
-// Everything else as dcb_nsplit: activations in LDS (A = [PX][CI], B = [PX][C], XOR-swizzled), persistent workgroups,
+// Otherwise: activations in LDS (A = [PX][CI], B = [PX][C], XOR-swizzled), persistent workgroups,
 // the next tile's t2 by LDS-DMA behind ffn.2's MFMAs, outputs stored straight from the epilogues' registers.
 #pragma once
-#include "dcb_nsplit_kernel.h"
+#include "dcb_nsplit_common.h"
 
 namespace dcvc {
 namespace nsplit8 {
@@ -510,7 +511,8 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
                     }
                     if constexpr (NEXT != 0) *slot = o;     // the NEXT slot's operand
                     const int m = m0 + 32 * t + pxv;
-                    if (m < p.M) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
+                    // (a block whose output only feeds the closing conv of its chain keeps it in LDS: y = null)
+                    if (m < p.M && (!FIN || p.y != nullptr)) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
                 }
     }
     if constexpr (NEXT != 0) __syncthreads();       // y complete in B

@@ -85,11 +85,12 @@ struct DcbNsplitDesc {
     bool shortcut = false;
     // round 6: instead of the next block's dc.0 the launch can run the 1x1 conv that CLOSES a chain (y_prior_fusion.conv.3,
     // y_spatial_prior.conv.3, decoder.conv2, recon_head.head ...): yfin = (Wfin y + bfin) [* qfin] -> fp16, width nfin.
-    // wfin = dcb_nsplit_pack_fin's stream. Bit-identical to conv1x1(bias [, q]) on y.
+    // wfin = dcb_nsplit_pack_fin's stream. Bit-identical to conv1x1(bias [, q]) on y. With a closing conv y may be null: the
+    // block's own output then never leaves LDS (nothing else reads it in the codecs).
     const half_t* wfin = nullptr; const half_t* bfin = nullptr; const half_t* qfin = nullptr;
     half_t* yfin = nullptr; int ldyfin = 0; int nfin = 0;
 };
-int dcb_nsplit_waves();                                      // 8 (round 4) or 4 (DCVC_NSPLIT_WAVES=4: round 3's kernel, A/B)
+int dcb_nsplit_waves();                                      // 8
 bool dcb_nsplit_shape(int c, int ci);                         // a shape the kernel is instantiated for
 bool dcb_nsplit_supported(int c, int cdc, int cffn);          // DCVC_NSPLIT: 0 = off, 1 = full-width blocks only (A/B)
 size_t dcb_nsplit_main_halves(int c, int ci);

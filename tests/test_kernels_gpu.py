@@ -701,6 +701,13 @@ def test_dcb_nsplit_closing_conv_equals_launch_sequence(ops, C, CI, NN, P, short
     bad = int((yf[:, :NN] != want_f).sum())
     assert bad == 0, "closing conv: %d of %d outputs differ" % (bad, want_f.numel())
     assert (yf[:, NN:] == 7.0).all(), "channels beyond the closing conv's width untouched"
+    if not shortcut:
+        # the codecs' form: nothing else reads the block's own output, so it is not stored at all (y = NULL)
+        yf2 = torch.full((P, NN + 8), 7.0, dtype=torch.half, device=dev)
+        call(ops.dcb_nsplit_fin, ptr(t2), CI, ptr(xbuf), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), None,
+             ptr(wf), ptr(bf), ptr(qf), ptr(yf2), NN + 8, NN, None, 0, P, C, CI, 0, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(yf2, yf), "closing conv without the block's own output"
 
 
 @pytest.mark.parametrize("CIN,C,CI,P", [
