@@ -55,6 +55,14 @@ constexpr int RING = NS8_RING;           // weight fragments in flight per wave 
 #ifndef NS8_RING1
 #define NS8_RING1 8
 #endif
+// how many k-slices ahead of their MFMAs the activation fragments are read from LDS: NS8_AHEAD where a slice has fewer than
+// four MFMAs (one tile per wave, or 32-pixel workgroups), NS8_AHEAD_WIDE where it has four or more
+#ifndef NS8_AHEAD
+#define NS8_AHEAD 2
+#endif
+#ifndef NS8_AHEAD_WIDE
+#define NS8_AHEAD_WIDE 1
+#endif
 #ifndef NS8_GATHERS
 #define NS8_GATHERS 8
 #endif
@@ -338,21 +346,29 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         constexpr int NT = decltype(nt_tag)::value;
         constexpr int KSN = decltype(ks_tag)::value;
         constexpr int F0 = decltype(f0_tag)::value;
-        half8 b[2][PXT];              // activation fragments, read one k-slice ahead of their MFMAs
+        // activation fragments, read AH k-slices ahead of their MFMAs (NS8_AHEAD; one slice is 32 NT PXT matrix-core cycles:
+        // with one tile per wave that does not cover a ds_read_b128 under load - round 6, profiles/r06_ahead.txt)
+        constexpr int AH = NT * PXT >= 4 ? NS8_AHEAD_WIDE : NS8_AHEAD;
+        half8 b[AH + 1][PXT];
+        static_for<0, AH>([&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            if constexpr (i < KSN) {
 #pragma unroll
-        for (int t = 0; t < PXT; ++t) b[0][t] = frag(t, 0);
+                for (int t = 0; t < PXT; ++t) b[i][t] = frag(t, i);
+            }
+        });
         static_for<0, KSN>([&](auto kt) {
             constexpr int ks = decltype(kt)::value;
-            if constexpr (ks + 1 < KSN) {
+            if constexpr (ks + AH < KSN) {
 #pragma unroll
-                for (int t = 0; t < PXT; ++t) b[(ks + 1) & 1][t] = frag(t, ks + 1);
+                for (int t = 0; t < PXT; ++t) b[(ks + AH) % (AH + 1)][t] = frag(t, ks + AH);
             }
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, NT>([&](auto j_tag) {
                 constexpr int j = NT - 1 - decltype(j_tag)::value;       // the slice's LAST fragment first: one counted wait per slice
                 const half8 a = ring[(F0 + ks * NT + j) % RING];
 #pragma unroll
-                for (int t = 0; t < PXT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks & 1][t], acc[j][t], 0, 0, 0);
+                for (int t = 0; t < PXT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks % (AH + 1)][t], acc[j][t], 0, 0, 0);
             });
             static_for<0, NT>([&](auto j_tag) { issue(std::integral_constant<int, F0 + ks * NT + decltype(j_tag)::value + RING>{}); });
             // nothing crosses a k-slice (left alone, hipcc sinks every prefetch load down to the MFMA that consumes it)

@@ -15,7 +15,7 @@ cd /tmp
 for w in intra ld hts htl; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof6_$w -o t -- python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-uhd --no-extras --no-roofline --no-pipeline --min-seconds 0 > $O/prof_$w.log 2>&1
   find /tmp/prof6_$w -name "t_kernel_stats.csv" -exec cp {} $O/${w}_kernel_stats.csv \;
-  case $w in intra|htl) M="y_step_enc"; P=4;; *) M="mask_step_enc"; P=2;; esac
+  case $w in intra|htl) M="y_step_enc"; P=4;; hts) M="mask_step_enc"; P=4;; *) M="mask_step_enc"; P=2;; esac
   python $R/tools/trace_after_setup.py /tmp/prof6_$w --marker $M --per $P > $O/${w}_per_picture.txt 2>&1
   head -14 $O/${w}_per_picture.txt
 done
