@@ -634,7 +634,7 @@ def cpu_baseline(cpu_net, device):
     }
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_hbm_traffic.json")
 KERNEL_SOURCES = ("dcb_nsplit8_kernel.h", "dcb_nsplit_common.h", "dcb_nsplit.hip", "dcb_pair8_kernel.h", "dcb_pair.hip", "conv_gemm.hip", "dcb_tail.hip", "ffn_fused.hip", "dwconv.hip",
                   "arith.h")
 

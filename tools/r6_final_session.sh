@@ -1,0 +1,50 @@
+#!/bin/bash
+# round 6, closing session (ONE gpurun call, ~ 30 minutes): box identity, the block bench for every shape, PMC traffic of the
+# bench's kernels, counters of the block kernel, the whole GPU suite, smoke(), the default bench line, kernel-trace summaries per
+# workload (+ launches per coded unit behind the set-up). Outputs under gpurun_out/r06/; the ones quoted in DESIGN.md are copied
+# to profiles/r06_*.
+set -x
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r06
+mkdir -p $O
+B=tools/_bin
+L=dcvc_amd/libdcvc_amd.so
+{ hostname; lscpu | grep -i "model name"; rocm-smi --showuniqueid --showproductname 2>/dev/null | grep -v "^=\|^$"; cat .git_head 2>/dev/null; } > $O/r06_box.txt 2>&1
+us=$(timeout 120 $B/core_bench -r 2 -n 10 $L | grep "dcb_nsplit + next" | head -1 | awk '{print $5}')
+echo "block kernel: $us us" | tee -a $O/r06_box.txt
+if [ -z "$us" ] || awk -v u="$us" 'BEGIN { exit !(u > 100) }'; then echo "SLOW BOX - stopping"; exit 7; fi
+{ for sh in "384 384 32640" "512 256 32640" "512 512 32640" "256 256 32640" "256 128 32640" "512 512 8160" "768 768 8160" "384 192 8160" "384 384 129600"; do
+    set -- $sh; echo "=== C $1 CI $2 pixels $3"
+    timeout 200 $B/core_bench -r 3 -n 20 -c $1 -i $2 -p $3 $L
+  done; } 2>&1 | grep "===\|dcb_nsplit + next\|dw3x3" | grep -o "===.*\|dcb_nsplit + next[^|]*|[^|]*\|dw3x3 *[0-9.]* us" > $O/r06_core_bench_shapes.txt
+cat $O/r06_core_bench_shapes.txt
+BENCH="python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --no-uhd --no-resolutions --no-pipeline --min-seconds 0"
+cd /tmp
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc6/bench_fetch -o bench_fetch -- $BENCH > $O/pmc_bench_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc6/bench_write -o bench_write -- $BENCH > $O/pmc_bench_write.log 2>&1
+cd $R
+python tools/hbm_traffic.py /tmp/pmc6/bench_fetch /tmp/pmc6/bench_write $O/r06_hbm_traffic.json "$(cat .git_head 2>/dev/null)" | grep -A5 "nsplit8_kernel<384"
+cp $O/r06_hbm_traffic.json profiles/r06_hbm_traffic.json
+# MFMA-busy / busy cycles of the block launches (core_bench, (384, 384) at 1080p / 8)
+cd /tmp
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pmc6/clk_lib -o clk -- $R/$B/core_bench -r 2 -n 10 $R/$L > $O/clk.log 2>&1
+cd $R
+python tools/pmc_summary.py /tmp/pmc6 2>/dev/null | grep -i "clk\|nsplit" | cut -c1-260 > $O/r06_block_counters.txt
+cat $O/r06_block_counters.txt
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -25 > $O/r06_test_gpu.log
+tail -6 $O/r06_test_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.log
+timeout 900 python bench.py > $O/r06_bench_line.json 2> $O/r06_bench.err
+tail -c 600 $O/r06_bench_line.json
+tail -2 $O/r06_bench.err
+cd /tmp
+for w in intra hts htl ld; do
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof6_$w -o t -- python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-uhd --no-resolutions --no-extras --no-roofline --no-pipeline --min-seconds 0 > $O/r06_prof_$w.log 2>&1
+  find /tmp/prof6_$w -name "t_kernel_stats.csv" -exec cp {} $O/r06_${w}_kernel_stats.csv \;
+  head -4 $O/r06_${w}_kernel_stats.csv | cut -c1-200
+  case $w in intra|htl) M="y_step_enc"; P=4;; hts) M="mask_step_enc"; P=4;; *) M="mask_step_enc"; P=2;; esac
+  python $R/tools/trace_after_setup.py /tmp/prof6_$w --marker $M --per $P > $O/r06_${w}_per_picture.txt 2>&1
+  head -12 $O/r06_${w}_per_picture.txt
+done
+cd $R
