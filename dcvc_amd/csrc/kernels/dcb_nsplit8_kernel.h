@@ -619,8 +619,16 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     }
 }
 
+// NS8_OCC2 (experiment, round 6): 32-pixel workgroups whose LDS image fits twice into a CU are compiled for 128 registers, so that
+// TWO workgroups share a CU (four waves per SIMD): the barrier / latency phases of one run under the contractions of the other
+#ifndef NS8_OCC2
+#define NS8_OCC2 0
+#endif
 template <int C, int CI, int PXT, int NEXT>
-__global__ void __launch_bounds__(NTHREADS, 2)
+constexpr int waves_per_simd() { return (NS8_OCC2 != 0 && PXT == 1 && Lay<C, CI, PXT, NEXT>::BYTES <= 80 * 1024) ? 4 : 2; }
+
+template <int C, int CI, int PXT, int NEXT>
+__global__ void __launch_bounds__(NTHREADS, (waves_per_simd<C, CI, PXT, NEXT>()))
 dcb_nsplit8_kernel(const NsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem8[];
@@ -657,7 +665,7 @@ void launch8(const NsParams& p, hipStream_t stream)
         hip_check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
         cu_count[dev] = n > 0 ? n : 256;
     });
-    const int cus = cu_count[dev];
+    const int cus = cu_count[dev] * (waves_per_simd<C, CI, PXT, NEXT>() / 2);     // persistent workgroups the chip holds at once
     const int tiles = (p.M + 32 * PXT - 1) / (32 * PXT);
     const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;
