@@ -149,6 +149,8 @@ struct NsplitPacked {
     dcvc::half_t* main = nullptr;
     dcvc::half_t* next = nullptr;
     hipEvent_t packed = nullptr;          // recorded behind the pack launches: dcvc_dcb_nsplit_packed on ANOTHER stream waits for it
+    hipStream_t pack_stream = nullptr;    // ... the stream they ran on needs no wait (and may be capturing: advisor, round 5)
+    mutable bool settled = false;         // the event has been seen complete: no launch waits for it any more
     NsplitPacked() = default;
     NsplitPacked(const NsplitPacked&) = delete;
     NsplitPacked& operator=(const NsplitPacked&) = delete;
@@ -288,6 +290,7 @@ int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const v
         }
         dcvc::hip_check(hipEventCreateWithFlags(&pk->packed, hipEventDisableTiming), "hipEventCreate");
         dcvc::hip_check(hipEventRecord(pk->packed, S(stream)), "hipEventRecord(packed)");
+        pk->pack_stream = S(stream);
         *handle = pk.release();
     });
 }
@@ -298,6 +301,14 @@ int dcvc_dcb_nsplit_free(void* handle)
         if (handle == nullptr) return;
         // ~NsplitPacked: synchronises the OWNING device (not whichever is current), then frees
         std::unique_ptr<NsplitPacked> pk(static_cast<NsplitPacked*>(handle));
+        // a failure of an earlier launch surfaces at this synchronisation: report it (the destructor cannot), then free anyway
+        int cur = 0;
+        dcvc::hip_check(hipGetDevice(&cur), "hipGetDevice");
+        if (cur != pk->device) dcvc::hip_check(hipSetDevice(pk->device), "hipSetDevice");
+        const hipError_t e = hipDeviceSynchronize();
+        if (cur != pk->device) (void)hipSetDevice(cur);
+        pk.reset();
+        dcvc::hip_check(e, "hipDeviceSynchronize(dcb_nsplit_free)");
     });
 }
 
@@ -313,8 +324,13 @@ int dcvc_dcb_nsplit_packed(const void* handle, const void* t2, int ldt, const vo
         dcvc::hip_check(hipGetDevice(&dev), "hipGetDevice");
         if (dev != pk->device) throw std::invalid_argument("dcb_nsplit_packed: the handle was packed on another device");
         if (with_next && pk->next == nullptr) throw std::invalid_argument("dcb_nsplit_packed: packed without the next block's dc.0");
-        // the pack launches ran on the stream given to _pack: any other stream orders itself behind them here
-        dcvc::hip_check(hipStreamWaitEvent(S(stream), pk->packed, 0), "hipStreamWaitEvent(packed)");
+        // the pack launches ran on the stream given to _pack: any OTHER stream orders itself behind them here, until the event has
+        // been seen complete once (a wait per launch is a barrier packet per launch; and a stream that is being captured must not
+        // wait for an event recorded outside the capture - pack and first launch belong in front of a capture)
+        if (S(stream) != pk->pack_stream && !pk->settled) {
+            if (hipEventQuery(pk->packed) == hipSuccess) pk->settled = true;
+            else dcvc::hip_check(hipStreamWaitEvent(S(stream), pk->packed, 0), "hipStreamWaitEvent(packed)");
+        }
         nsplit_launch(pk->main, with_next ? pk->next : nullptr, t2, ldt, x, ldx, b3, b0, b2, q, q2, b1n, t1n, ldt1, y, ldy, pixels,
                       pk->c, pk->ci, shortcut, S(stream));
     });

@@ -590,6 +590,15 @@ void launch(ConvGemmParams p, hipStream_t stream)
             return;
         }
     }
+    if constexpr (!CHUNK) {
+        // narrow layers on small grids (the 3x3 stride-2 conv behind LD's encoder: 8160 x 128 outputs, K = 2304) leave half the
+        // chip idle with 64 x 128 tiles: 64 x 64 ones (round 6)
+        const long long tiles64x128 = static_cast<long long>((p.M + 63) / 64) * ((p.N + 127) / 128);
+        if (tiles64x128 <= 160 && p.K >= 512 && (!UPSAMPLE || p.up_cout % 64 == 0)) {
+            launch_cfg<2, 2, 1, 1, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
+            return;
+        }
+    }
     if (tiles128 < 640) {
         launch_cfg<2, 2, 1, 2, 2, SPATIAL, ACT, CHUNK, NRES, QUANT, UPSAMPLE>(p, stream);
     } else {

@@ -24,6 +24,7 @@
 #include "ops.h"
 
 #include <cstdlib>
+#include <stdexcept>
 #include <string>
 
 namespace dcvc {
@@ -172,7 +173,9 @@ int variant()
         if (s == "16,1") return 4;
         if (s == "16,2") return 5;
         if (s == "8,3") return 6;
-        return 0;
+        if (s == "8,1") return 0;
+        // (a typo used to select round 1's kernel silently: advisor, round 5)
+        throw std::invalid_argument("DCVC_DWCONV_VARIANT: unknown value '" + s + "' (8,1 | 8,2 | 8,3 | 4,1 | 4,2 | 16,1 | 16,2)");
     }();
     return v;
 }

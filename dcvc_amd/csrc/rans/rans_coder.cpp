@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
@@ -312,6 +313,17 @@ void CdfTable::load(const int32_t* cdfs, int num_cdf, int row_stride, const int3
         if (size < 2 || size > stride || row[0] != 0) vector_ok = false;
         for (int j = 1; vector_ok && j < size; ++j) {
             if (row[j] == 0 || row[j] < row[j - 1] || row[j] > (1u << kRansProbBits)) vector_ok = false;
+        }
+        // ... and ends at the full range: a row that does not is malformed, and the two searches would decode it differently
+        if (vector_ok && row[size - 1] != (1u << kRansProbBits)) vector_ok = false;
+    }
+    // one non-conforming row keeps the WHOLE table on the portable search: said once, so that the slower decode path is visible
+    if (!vector_ok && stride <= kEdgeRow + 1 && kRansProbBits == 16 && cpu_has_avx512bw() && getenv("DCVC_RANS_AVX512") == nullptr) {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            fprintf(stderr, "[dcvc] rANS decoder: a CDF table (%d rows) is not of the form the vector search needs "
+                            "(0 = cdf[0] < cdf[1] <= ... <= cdf[size - 1] = 65536): portable search for it\n", num);
         }
     }
     if (vector_ok) {

@@ -257,6 +257,24 @@ def recv_state(proxy, src, height, width, dist, device=None):
     state = cache[1]
     dist.recv(state, src)
     if not state.is_cuda and _has_gpu():
-        state = state.cuda()                     # gloo on a GPU box: the transfer went through host memory
+        # gloo on a GPU box: the transfer went through host memory; the device staging copy is cached with the receive buffer
+        dev_buf = cache[2] if len(cache) > 2 else None
+        if dev_buf is None or dev_buf.numel() != state.numel():
+            dev_buf = torch.empty(state.numel(), dtype=torch.uint8, device="cuda")
+            try:
+                proxy._state_rx = (cache[0], cache[1], dev_buf)
+            except AttributeError:
+                pass
+        dev_buf.copy_(state)
+        state = dev_buf
     proxy.import_state(state, height, width)
     return state.numel()
+
+
+def release_state_buffers(proxy):
+    """Drops the receive / staging buffers recv_state() keeps on a proxy (84 MB per encoder or decoder object at 1080p, about
+    4x that at 3840x2160) - for a rank that will not take over a stream again. The next recv_state() allocates them anew."""
+    try:
+        del proxy._state_rx
+    except AttributeError:
+        pass

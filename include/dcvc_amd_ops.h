@@ -110,7 +110,9 @@ int dcvc_dcb_pair_supported(int cin, int c, int ci);
 
 /* Handle form: pack w3 | w0 | w2 (and w1n, or NULL) once - the packed copies are a snapshot of the weights at pack time -,
  * launch any number of times, free (synchronises the device the handle was packed on, whichever is current). `stream` of
- * _pack and of _packed may differ: _packed orders its stream behind the pack launches (an event recorded by _pack).
+ * _pack and of _packed may differ: _packed orders its stream behind the pack launches (an event recorded by _pack; only until
+ * the event has been seen complete, and never on the pack stream itself). A stream that is being CAPTURED into a hipGraph must not
+ * be the first to launch with a handle packed on another stream: pack and first launch belong in front of the capture.
  * with_next != 0 runs the next block's dc.0 inside the launch (the handle must have been packed with w1n). No reference counterpart: the reference's CUTLASS kernels read the
  * row-major matrices directly. */
 int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const void* w1n, int c, int ci, void* stream,

@@ -89,7 +89,7 @@ def main():
             xh = x_hat[0].permute(1, 2, 0).numpy().clip(-0.5, 0.5)[:H, :W]
             src = x.astype(np.float32)
             name = "dmci_%dx%d_q%d_noskip" % (W, H, qp)
-            keep = {k: v for k, v in out.get(name, {}).items() if k.startswith("oracle_") or k == "crop_psnr_floor"}
+            keep = {k: v for k, v in out.get(name, {}).items() if k.startswith("oracle_") or k.startswith("crop_psnr_")}
             y0, x0 = crop_window(H, W)
             crops[name] = xh[y0:y0 + CROP, x0:x0 + CROP].astype(np.float16)
             out[name] = {

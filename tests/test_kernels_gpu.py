@@ -53,6 +53,8 @@ CONV_CASES = [
     dict(P=2048, K=384, N=1536, wsilu=True, chunk=True, name="bias_wsilu_chunk_add_384"),
     dict(P=129, K=512, N=192, q2=True, name="bias_then_scale_n192"),
     dict(P=4096, K=2048, N=512, name="bias_k2048"),
+    dict(P=5000, K=1024, N=128, r1=True, q=True, name="narrow_small_grid_64x64"),
+    dict(P=777, K=512, N=64, wsilu=True, name="narrow_small_grid_64x64_wsilu"),
     # 1080p-sized grids: the 256-pixel tile shapes (256x256 and 256x192), ragged last tile
     dict(P=32641, K=384, N=1536, wsilu=True, chunk=True, name="p8_chunk_add_256x256"),
     dict(P=32600, K=384, N=384, r1=True, name="p8_shortcut_256x192"),
@@ -113,7 +115,9 @@ def test_conv1x1(ops, case):
 
 
 @pytest.mark.parametrize("k,s,p,H,W,cin,cout", [(3, 2, 1, 18, 30, 128, 128), (2, 2, 0, 34, 60, 64, 128),
-                                                (3, 1, 1, 17, 15, 64, 256), (3, 2, 1, 17, 31, 192, 256)])
+                                                (3, 1, 1, 17, 15, 64, 256), (3, 2, 1, 17, 31, 192, 256),
+                                                # round 6: 64 x 64 tiles for narrow layers on small grids (LD's encoder.down at 1080p)
+                                                (3, 2, 1, 136, 240, 256, 128), (3, 2, 1, 70, 100, 256, 128)])
 def test_conv_kxk(ops, k, s, p, H, W, cin, cout):
     from gpu_util import call, ptr, stream, nhwc
     dev = "cuda"
@@ -173,7 +177,7 @@ def test_dwconv3x3(ops, H, W, C):
     assert torch.equal(ys[:, :, 16:16 + C], y) and float(ys[:, :, :16].abs().max()) == 0 and float(ys[:, :, 16 + C:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("variant", ["8,1", "8,2", "4,2", "16,1", "8,3"])
+@pytest.mark.parametrize("variant", ["8,1", "8,2", "8,3", "4,1", "4,2", "16,1", "16,2"])      # every selectable instantiation
 def test_dwconv3x3_other_variants(variant):
     """the other instantiations of the depthwise walk (rows per lane, rows of loads in flight; DCVC_DWCONV_VARIANT, read once
     per process): same arithmetic, same bits; prints the launch time of each at 1080p / 8"""
@@ -183,7 +187,20 @@ def test_dwconv3x3_other_variants(variant):
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-s", "-k",
                           "test_dwconv3x3 and not other_variants", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     print("\n".join(l for l in res.stdout.splitlines() if "us per launch" in l))
-    assert res.returncode == 0 and "11 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]
+    import re
+    m = re.search(r"(\d+) passed", res.stdout)
+    assert res.returncode == 0 and m and int(m.group(1)) >= 10 and "failed" not in res.stdout, res.stdout[-3000:] + res.stderr[-1000:]
+
+
+def test_dwconv3x3_unknown_variant_is_refused():
+    """a typo in DCVC_DWCONV_VARIANT used to select round 1's kernel silently (advisor, round 5): now an error"""
+    import subprocess
+    import sys
+    code = ("import torch, sys; sys.path.insert(0, %r); import gpu_util as g; ops = g.Ops(); "
+            "x = torch.zeros((8, 8, 64), dtype=torch.half, device='cuda'); w = torch.zeros((9, 64), dtype=torch.half, device='cuda'); "
+            "g.call(ops.dwconv3x3, g.ptr(x), 64, g.ptr(w), g.ptr(x.clone()), 64, 8, 8, 64, g.stream())" % os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DCVC_DWCONV_VARIANT="8,4"), capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "DCVC_DWCONV_VARIANT" in (res.stderr + res.stdout), res.stderr[-1500:]
 
 
 def test_dwconv3x3_launch_time(ops):
