@@ -16,7 +16,7 @@ echo "block kernel: $us us" | tee -a $O/r06_box.txt
 if [ -z "$us" ] || awk -v u="$us" 'BEGIN { exit !(u > 100) }'; then echo "SLOW BOX - stopping"; exit 7; fi
 { for sh in "384 384 32640" "512 256 32640" "512 512 32640" "256 256 32640" "256 128 32640" "512 512 8160" "768 768 8160" "384 192 8160" "384 384 129600"; do
     set -- $sh; echo "=== C $1 CI $2 pixels $3"
-    timeout 200 $B/core_bench -r 3 -n 20 -c $1 -i $2 -p $3 $L
+    if [ $3 = 32640 ]; then timeout 200 $B/core_bench -r 3 -n 20 -c $1 -i $2 $L; else timeout 200 $B/core_bench -r 3 -n 20 -c $1 -i $2 -p $3 $L; fi
   done; } 2>&1 | grep "===\|dcb_nsplit + next\|dw3x3" | grep -o "===.*\|dcb_nsplit + next[^|]*|[^|]*\|dw3x3 *[0-9.]* us" > $O/r06_core_bench_shapes.txt
 cat $O/r06_core_bench_shapes.txt
 BENCH="python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --no-uhd --no-resolutions --no-pipeline --min-seconds 0"
@@ -32,7 +32,7 @@ timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VAL
 cd $R
 python tools/pmc_summary.py /tmp/pmc6 2>/dev/null | grep -i "clk\|nsplit" | cut -c1-260 > $O/r06_block_counters.txt
 cat $O/r06_block_counters.txt
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -25 > $O/r06_test_gpu.log
+timeout 2400 python -m pytest tests -m gpu -q -rs 2>&1 | tail -25 > $O/r06_test_gpu.log
 tail -6 $O/r06_test_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.log
 timeout 900 python bench.py > $O/r06_bench_line.json 2> $O/r06_bench.err
@@ -48,3 +48,9 @@ for w in intra hts htl ld; do
   head -12 $O/r06_${w}_per_picture.txt
 done
 cd $R
+# per-shape timing of the contraction launches (bench.py's event-stamped pass)
+for w in ld intra hts htl; do
+  DCVC_BENCH_SHAPES=$O/r06_gemm_shapes_$w.csv timeout 300 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-uhd --no-resolutions --no-extras --no-pipeline --min-seconds 0 > /dev/null 2>&1
+done
+# round 6 against round 5's library on this box (tools/_bin/r05.so, when it travelled with the tree)
+if [ -f tools/_bin/r05.so ]; then bash tools/r6_ab_round.sh 2>/dev/null | grep "^pass" > $O/r06_round_ab_closing.txt; cat $O/r06_round_ab_closing.txt; fi
