@@ -171,7 +171,7 @@ struct NsplitPacked {
 void nsplit_check_shape(int c, int ci)
 {
     if (!dcvc::dcb_nsplit_shape(c, ci)) {
-        throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256) or (256, 128)");
+        throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256), (256, 128), (384, 192) or (192, 192)");
     }
 }
 

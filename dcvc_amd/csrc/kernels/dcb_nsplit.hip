@@ -12,11 +12,40 @@ namespace {
 // lane l holds row (l & 31), k = 8 (l >> 5) .. + 7. Order inside a wave's stream = the order the kernel consumes.
 // the kernel's streams (dcb_nsplit8_kernel.h): waves 0 .. 3, then 4 .. 7; waves w and w + 4 share the tiles
 // [simd QC, (simd + 1) QC) of a C-wide layer (w the first HI, w + 4 the remaining LO); ffn.0: N0 tiles per wave in passes of 2
+// Geo<> on the host: tiles per wave of an N-wide layer. N a multiple of 128: by SIMD pair (HI = first share, LO = the rest);
+// otherwise (192) by the closing convs' rule: waves 0 .. 3 `hi` tiles each, the first `act` of the waves 4 .. 7 `lo` each.
+struct Share {
+    int hi, lo, act;
+    bool by_pair;
+    __host__ __device__ explicit Share(int n)
+    {
+        by_pair = n % 128 == 0;
+        if (by_pair) {
+            const int q = n / 128;
+            hi = (q + 1) / 2; lo = q / 2; act = 4;
+        } else {
+            const int tn = n / 32;
+            hi = (tn + 7) / 8;
+            const int rem = tn - 4 * hi;
+            lo = rem <= 0 ? 0 : (rem + 3) / 4;
+            act = lo == 0 ? 0 : rem / lo;
+        }
+    }
+    // first tile of wave `w` (0 .. 7) and whether it has a share at all
+    __host__ __device__ int first_tile(int w, int n) const
+    {
+        if (by_pair) return (w & 3) * (n / 128) + (w < 4 ? 0 : hi);
+        return w < 4 ? w * hi : 4 * hi + (w - 4) * lo;
+    }
+    __host__ __device__ bool on(int w) const { return by_pair || w < 4 || w - 4 < act; }
+};
+
 __global__ void pack_main8_kernel(const half_t* w3, const half_t* w0, const half_t* w2, int C, int CI, half8* out)
 {
-    const int KS_C = C / 16, KS_I = CI / 16, QC = C / 128, HI_C = (QC + 1) / 2, LO_C = QC / 2, TP = 2;
+    const int KS_C = C / 16, KS_I = CI / 16, TP = 2;
+    const Share sc(C);
     const int PAIRS = CI / 16, P0_HI = (PAIRS + 7) / 8, P0_LO = (PAIRS - 4 * P0_HI) / 4;       // Geo<>: ffn.0 tile pairs per wave (CI = 192: 2 | 1)
-    const int FM_HI = 2 * HI_C * KS_I + 2 * P0_HI * KS_C, FM_LO = 2 * LO_C * KS_I + 2 * P0_LO * KS_C;
+    const int FM_HI = 2 * sc.hi * KS_I + 2 * P0_HI * KS_C, FM_LO = 2 * sc.lo * KS_I + 2 * P0_LO * KS_C;
     const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (u >= 4LL * (FM_HI + FM_LO) * 64) return;
     const int lane = static_cast<int>(u & 63);
@@ -24,21 +53,24 @@ __global__ void pack_main8_kernel(const half_t* w3, const half_t* w0, const half
     const bool hiw = F < 4 * FM_HI;
     const int wave = hiw ? F / FM_HI : 4 + (F - 4 * FM_HI) / FM_LO;
     const int f = hiw ? F % FM_HI : (F - 4 * FM_HI) % FM_LO;
-    const int simd = wave & 3, NT = hiw ? HI_C : LO_C, F_DC3 = NT * KS_I, F_FFN0 = 2 * (hiw ? P0_HI : P0_LO) * KS_C;
-    const int cb = 32 * (simd * QC + (hiw ? 0 : HI_C));
+    const int NT = hiw ? sc.hi : sc.lo, F_DC3 = NT * KS_I, F_FFN0 = 2 * (hiw ? P0_HI : P0_LO) * KS_C;
+    const int cb = 32 * sc.first_tile(wave, C);
     const int cb0 = hiw ? wave * 64 * P0_HI : 4 * 64 * P0_HI + (wave - 4) * 64 * P0_LO;       // the wave's first ffn.0 channel
     const half_t* w;
     int n0, ks, K;
+    bool zero = false;             // a wave without a share of the C-wide layers walks a tile of zeros (block width 192: waves 6, 7)
     if (f < F_DC3) {                                  // dc.3 [C][CI]
-        ks = f / NT; n0 = cb + 32 * (f % NT); w = w3; K = CI;
+        ks = f / NT; n0 = cb + 32 * (f % NT); w = w3; K = CI; zero = !sc.on(wave);
     } else if (f < F_DC3 + F_FFN0) {                  // ffn.0 [4 CI][C]
         const int g = f - F_DC3, pass = g / (TP * KS_C), r = g % (TP * KS_C);
         ks = r / TP; n0 = cb0 + pass * 32 * TP + 32 * (r % TP); w = w0; K = C;
     } else {                                          // ffn.2 [C][CI]
         const int g = f - F_DC3 - F_FFN0;
-        ks = g / NT; n0 = cb + 32 * (g % NT); w = w2; K = CI;
+        ks = g / NT; n0 = cb + 32 * (g % NT); w = w2; K = CI; zero = !sc.on(wave);
     }
-    out[u] = *reinterpret_cast<const half8*>(w + static_cast<size_t>(n0 + (lane & 31)) * K + 16 * ks + 8 * (lane >> 5));
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!zero) v = *reinterpret_cast<const half8*>(w + static_cast<size_t>(n0 + (lane & 31)) * K + 16 * ks + 8 * (lane >> 5));
+    out[u] = v;
 }
 
 __global__ void pack_dc08_kernel(const half_t* w1, int C, int CI, half8* out)       // dc.0 [CI][C]
@@ -84,7 +116,8 @@ bool dcb_nsplit_shape(int c, int ci)
 {
     return (c == 384 && ci == 384) || (c == 512 && ci == 512) || (c == 768 && ci == 768) || (c == 256 && ci == 256) ||
            (c == 512 && ci == 256) || (c == 256 && ci == 128) ||
-           (c == 384 && ci == 192);       // round 6: the LD model's prior fusion blocks
+           (c == 384 && ci == 192) ||     // round 6: the LD model's prior fusion blocks
+           (c == 192 && ci == 192);       // ... and the intra decoder's last block
 }
 
 // widths of a chain-closing conv the 8-wave kernel of a block shape is instantiated for (dcb_nsplit8_<shape>_fin.hip)
@@ -105,8 +138,13 @@ void dcb_nsplit_timeline_buffer(long long* device_buffer)
     g_ns_timeline = device_buffer;
 }
 
-// fragments of 512 halves: dc.3 and ffn.2 (c / 32 tiles x ci / 16 slices each), ffn.0 (4 ci / 32 tiles x c / 16 slices)
-size_t dcb_nsplit_main_halves(int c, int ci) { return (2ull * (c / 32) * (ci / 16) + 1ull * (ci / 8) * (c / 16)) * 512; }
+// fragments of 512 halves: dc.3 and ffn.2 (the waves' tiles x ci / 16 slices each - incl. the zero tiles of waves without a share),
+// ffn.0 (4 ci / 32 tiles x c / 16 slices)
+size_t dcb_nsplit_main_halves(int c, int ci)
+{
+    const Share sc(c);
+    return (2ull * 4 * (sc.hi + sc.lo) * (ci / 16) + 1ull * (ci / 8) * (c / 16)) * 512;
+}
 size_t dcb_nsplit_dc0_halves(int c, int ci)
 {
     // an inner width that is no multiple of 128 (192): tiles by wave as a closing conv's, with the streams of the idle waves
@@ -121,7 +159,7 @@ size_t dcb_nsplit_fin_halves(int c, int nn)      // (declared in ops.h)
 
 void dcb_nsplit_pack_fin(const half_t* w, int c, int nn, half_t* out, hipStream_t stream)
 {
-    if (nn % 32 != 0 || nn < 128 || c % 128 != 0) throw std::invalid_argument("dcb_nsplit: unsupported closing conv");
+    if (nn % 32 != 0 || nn < 128 || c % 64 != 0) throw std::invalid_argument("dcb_nsplit: unsupported closing conv");
     const long long units = static_cast<long long>(dcb_nsplit_fin_halves(c, nn) / 8);
     hipLaunchKernelGGL(pack_fin8_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, stream, w, c, nn, reinterpret_cast<half8*>(out));
     hip_check(hipGetLastError(), "dcb_nsplit pack");
@@ -172,7 +210,7 @@ bool dcb_nsplit_supported(int c, int cdc, int cffn)
 void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
 {
     if (!dcb_nsplit_shape(d.c, d.ci)) {
-        throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256), (256, 128) or (384, 192)");
+        throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256), (256, 128), (384, 192) or (192, 192)");
     }
     if (d.pixels <= 0) throw std::invalid_argument("dcb_nsplit: empty problem");
     if ((d.ldt % 8) || (d.ldx % 8) || (d.ldy % 8) || (d.wnext && d.ldt1 % 8)) {
@@ -202,7 +240,8 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     static const bool narrow_all = [] { const char* e = getenv("DCVC_NSPLIT_PX"); return e != nullptr && atoi(e) == 32; }();
     const bool wide = d.pixels >= 64 * 200 && d.c < 768 && !narrow_all;
     const int next = d.wfin != nullptr ? d.nfin : d.wnext != nullptr ? 1 : 0;
-    if (d.c == 384 && d.ci == 192) nsplit8::run_384_192(p, wide, next, stream);
+    if (d.c == 192) nsplit8::run_192_192(p, wide, next, stream);
+    else if (d.c == 384 && d.ci == 192) nsplit8::run_384_192(p, wide, next, stream);
     else if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
     else if (d.c == 768) nsplit8::run_768_768(p, wide, next, stream);
     else if (d.c == 512 && d.ci == 512) nsplit8::run_512_512(p, wide, next, stream);

@@ -80,7 +80,8 @@ struct Lay {
     // LDS rows are swizzled in groups of 16 chunks (256 bytes): an inner width of 192 (the LD model's (384, 192) prior
     // fusion blocks) lives in rows of 256 channels, a third of them never read
     static constexpr int CIP = (CI + 127) / 128 * 128;
-    static constexpr int BUF_A = 32 * PXT * CIP * 2, BUF_B = 32 * PXT * C * 2;
+    static constexpr int CP = (C + 127) / 128 * 128;                     // (likewise the C-wide tensors: the intra decoder's last block is 192 wide)
+    static constexpr int BUF_A = 32 * PXT * CIP * 2, BUF_B = 32 * PXT * CP * 2;
     static constexpr int NB = NEXT > 1 ? NEXT : CI;                      // bias floats of the NEXT slot (dc.0: CI, closing conv: NN)
     static constexpr int BIAS_FLOATS = 2 * C + 4 * CI + NB;
     static constexpr int CONSTS = BIAS_FLOATS * 4 + 2 * C * 2;
@@ -113,8 +114,12 @@ struct Geo {
     static constexpr int TP = 2;                                        // passes of 2 tiles
     static constexpr int n0(bool hiw) { return 2 * (hiw ? P0_HI : P0_LO); }      // ffn.0 tiles per wave
     static constexpr int np(bool hiw) { return hiw ? P0_HI : P0_LO; }
-    static constexpr bool EVEN = HI_C == LO_C && HI_I == LO_I && I_BY_PAIR && P0_HI == P0_LO;
-    static constexpr int nt_c(bool hiw) { return hiw ? HI_C : LO_C; }
+    // C a multiple of 128: the C-wide layers' tiles by SIMD pair; otherwise (C = 192) by the closing convs' rule - the waves
+    // without a tile (6, 7) still walk a tile of ZERO weights through dc.3 / ffn.2 (one barrier sequence, one ring discipline)
+    // and keep their results to themselves
+    static constexpr bool C_BY_PAIR = C % 128 == 0;
+    static constexpr bool EVEN = HI_C == LO_C && HI_I == LO_I && I_BY_PAIR && C_BY_PAIR && P0_HI == P0_LO;
+    static constexpr int nt_c(bool hiw) { return C_BY_PAIR ? (hiw ? HI_C : LO_C) : (nt_f(C, hiw) > 0 ? nt_f(C, hiw) : 0); }
     static constexpr int nt_i(bool hiw) { return I_BY_PAIR ? (hiw ? HI_I : LO_I) : nt_f(CI, hiw); }
     static constexpr int f_dc3(bool hiw) { return nt_c(hiw) * KS_I; }
     static constexpr int f_ffn0(bool hiw) { return n0(hiw) * KS_C; }
@@ -132,7 +137,7 @@ struct Geo {
     static constexpr int nt_next(int next, bool hiw) { return next == 0 ? 0 : next == 1 ? nt_i(hiw) : nt_f(next, hiw); }
     static constexpr int f_next(int next, bool hiw) { return nt_next(next, hiw) * KS_C; }
     static constexpr bool even(int next) { return EVEN && (next <= 1 || (nf_hi(next) == nf_lo(next) && act_lo(next) == 4)); }
-    static_assert(C % 128 == 0 && CI % 64 == 0 && 4 * (P0_HI + P0_LO) == PAIRS && P0_LO >= 1, "channel counts the eight waves can share");
+    static_assert(C % 64 == 0 && CI % 64 == 0 && 4 * (P0_HI + P0_LO) == PAIRS && P0_LO >= 1, "channel counts the eight waves can share");
 };
 
 template <int C, int CI, int PXT, int NEXT, bool HIW>
@@ -143,14 +148,16 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     constexpr bool FIN = NEXT > 1;                                  // the NEXT slot is a chain-closing conv of width NEXT
     static_assert(!FIN || G::fin_ok(NEXT), "closing conv: a width the eight waves can share");
     static_assert(G::I_BY_PAIR || G::fin_ok(CI), "dc.0: an inner width the eight waves can share");
+    static_assert(G::C_BY_PAIR || G::fin_ok(C), "a block width the eight waves can share");
     constexpr int PX = 32 * PXT;
     constexpr int KS_C = G::KS_C, KS_I = G::KS_I;
     constexpr int NT_C = G::nt_c(HIW), NP = G::np(HIW), TP = G::TP;
     constexpr int F_DC3 = G::f_dc3(HIW), F_FFN0 = G::f_ffn0(HIW), F_MAIN = G::f_main(HIW), F_DC0 = G::f_next(NEXT, HIW);
     constexpr int NT_N = G::nt_next(NEXT, HIW);                     // this wave's 32-channel tiles of the NEXT slot
     constexpr int CIP = Lay<C, CI, PXT, NEXT>::CIP;            // LDS row of the CI-wide tensors (padded to 16-chunk groups)
-    constexpr int CH_C = C / 8, CH_I = CIP / 8;                 // 16-byte chunks per LDS row
-    constexpr int PITCH_C = C * 2, PITCH_I = CIP * 2;
+    constexpr int CP = Lay<C, CI, PXT, NEXT>::CP;
+    constexpr int CH_C = CP / 8, CH_I = CIP / 8;                // 16-byte chunks per LDS row
+    constexpr int PITCH_C = CP * 2, PITCH_I = CIP * 2;
     using L = Lay<C, CI, PXT, NEXT>;
     constexpr bool TRIPLE = L::TRIPLE;
     constexpr int RT = L::RT;
@@ -176,7 +183,12 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     // first channel of this wave's share of a C-wide / CI-wide layer, of ffn.0's 4 CI channels, of t
     // (HIW = the body of the waves with the larger share; where the shares are equal every wave runs it)
     const bool upper = wave >= 4;
-    const int cb_c = 32 * (simd * G::QC + (upper ? G::HI_C : 0));
+    const int cb_c = G::C_BY_PAIR ? 32 * (simd * G::QC + (upper ? G::HI_C : 0))
+                   : HIW ? 32 * wave * G::nf_hi(C) : 32 * (4 * G::nf_hi(C) + (wave - 4) * G::nf_lo(C));
+    // (C = 192: the waves 6 and 7 own no tile of the C-wide layers: their "tile" lies in the padding of the LDS rows, its weights are
+    // zeros, nothing of it is loaded from or stored to memory)
+    const bool c_on = G::C_BY_PAIR || HIW || (wave - 4) < G::act_lo(C);
+    const int cb_x = c_on ? cb_c : 0;
     const int cb_0 = HIW ? wave * (32 * G::n0(true)) : 4 * 32 * G::n0(true) + (wave - 4) * (32 * G::n0(false));
     // the NEXT slot: first channel of this wave's share, and whether it has one (closing conv of 192 channels: waves 6, 7 idle)
     constexpr bool BY_PAIR = !FIN && G::I_BY_PAIR;                   // dc.0 of a block whose inner width is a multiple of 128
@@ -266,7 +278,7 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     auto load_x = [&](int first_row) {
 #pragma unroll
         for (int t = 0; t < PXT; ++t) {
-            const half_t* const row = p.x + static_cast<size_t>(min(first_row + 32 * t + pxv, p.M - 1)) * p.ldx + (cb_c + 8 * hiv);
+            const half_t* const row = p.x + static_cast<size_t>(min(first_row + 32 * t + pxv, p.M - 1)) * p.ldx + (cb_x + 8 * hiv);
 #pragma unroll
             for (int j = 0; j < NT_C; ++j)
 #pragma unroll
@@ -508,7 +520,7 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
                     for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(y1[e]);
                     if (p.shortcut) {
                         const int m = min(m0 + 32 * t + px, p.M - 1);
-                        const half8 r8 = *reinterpret_cast<const half8*>(p.x + static_cast<size_t>(m) * p.ldx + ch + 8 * hi);
+                        const half8 r8 = *reinterpret_cast<const half8*>(p.x + static_cast<size_t>(m) * p.ldx + (cb_x + 32 * j + 16 * pr) + 8 * hi);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] + static_cast<float>(r8[e]);
                     }
@@ -528,7 +540,7 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
                     if constexpr (NEXT != 0) *slot = o;     // the NEXT slot's operand
                     const int m = m0 + 32 * t + pxv;
                     // (a block whose output only feeds the closing conv of its chain keeps it in LDS: y = null)
-                    if (m < p.M && (!FIN || p.y != nullptr)) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
+                    if (m < p.M && c_on && (!FIN || p.y != nullptr)) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
                 }
     }
     if constexpr (NEXT != 0) __syncthreads();       // y complete in B
@@ -701,6 +713,7 @@ void run_shape8(const NsParams& p, bool wide, int next, hipStream_t stream)
 // dcb_nsplit8_<shape>.hip
 void run_256_128(const NsParams& p, bool wide, int next, hipStream_t stream);
 void run_256_256(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_192_192(const NsParams& p, bool wide, int next, hipStream_t stream);
 void run_384_192(const NsParams& p, bool wide, int next, hipStream_t stream);
 void run_384_384(const NsParams& p, bool wide, int next, hipStream_t stream);
 void run_512_256(const NsParams& p, bool wide, int next, hipStream_t stream);

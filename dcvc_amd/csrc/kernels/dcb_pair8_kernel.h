@@ -39,12 +39,13 @@ struct PairParams {
 template <int CIN, int C, int CI, int PXT>
 struct Lay {
     static constexpr int CINP = (CIN + 127) / 128 * 128;              // LDS rows in groups of 16 chunks
-    static constexpr int BUF_A = 32 * PXT * CINP * 2, BUF_B = 32 * PXT * C * 2;
+    static constexpr int CP = (C + 127) / 128 * 128;                  // (block width 192: the intra decoder's last block)
+    static constexpr int BUF_A = 32 * PXT * CINP * 2, BUF_B = 32 * PXT * CP * 2;
     static constexpr int RT = 4;
     static constexpr int OFF_B = BUF_A;
     static constexpr int OFF_TABLE = nsplit::align16k(BUF_A + BUF_B);
     static constexpr int OFF_BIAS = OFF_TABLE + RT * TABLE_BYTES;
-    static constexpr int BYTES = OFF_BIAS + (C + CI) * 4;
+    static constexpr int BYTES = OFF_BIAS + (CP + CI) * 4;
     static constexpr bool FITS = BYTES <= 160 * 1024;
 };
 
@@ -57,11 +58,12 @@ __device__ __forceinline__ void pair_body(const PairParams& p, char* const smem)
     constexpr int KS_A = CIN / 16, KS_C = C / 16;
     constexpr int NT_C = G::nt_c(HIW), NT_N = G::nt_i(HIW);
     constexpr int F_A = NT_C * KS_A, F_1 = NT_N * KS_C, TOTAL = F_A + F_1;
-    constexpr int CH_A = L::CINP / 8, PITCH_A = L::CINP * 2, PITCH_C = C * 2;
+    constexpr int CH_A = L::CINP / 8, PITCH_A = L::CINP * 2, PITCH_C = L::CP * 2;
     constexpr int RT = L::RT;
     constexpr int OFF_B = L::OFF_B, OFF_TABLE = L::OFF_TABLE, OFF_BIAS = L::OFF_BIAS;
     static_assert(CIN % 64 == 0 && (PX * CH_A) % NTHREADS == 0, "input rows must split evenly over the threads");
     static_assert(G::I_BY_PAIR || G::fin_ok(CI), "dc.0: an inner width the eight waves can share");
+    static_assert(G::C_BY_PAIR || G::fin_ok(C), "a block width the eight waves can share");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,7 +76,9 @@ __device__ __forceinline__ void pair_body(const PairParams& p, char* const smem)
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)smem));
     if ((lds_base & 16383u) != 0) __builtin_trap();
     const bool upper = wave >= 4;
-    const int cb_c = 32 * (simd * G::QC + (upper ? G::HI_C : 0));
+    const int cb_c = G::C_BY_PAIR ? 32 * (simd * G::QC + (upper ? G::HI_C : 0))
+                   : HIW ? 32 * wave * G::nf_hi(C) : 32 * (4 * G::nf_hi(C) + (wave - 4) * G::nf_lo(C));
+    const bool c_on = G::C_BY_PAIR || HIW || (wave - 4) < G::act_lo(C);     // (block width 192: waves 6, 7 walk a tile of zeros)
     constexpr bool BY_PAIR = G::I_BY_PAIR;
     const int cb_n = BY_PAIR ? 32 * (simd * G::QI + (upper ? G::HI_I : 0))
                    : HIW ? 32 * wave * G::nf_hi(CI) : 32 * (4 * G::nf_hi(CI) + (wave - 4) * G::nf_lo(CI));
@@ -86,10 +90,10 @@ __device__ __forceinline__ void pair_body(const PairParams& p, char* const smem)
         t[tid] = p.wsilu[tid / RT];
         t[tid + NTHREADS] = p.wsilu[(tid + NTHREADS) / RT];
         float* lb = reinterpret_cast<float*>(smem + OFF_BIAS);
-        for (int i = tid; i < C + CI; i += NTHREADS) lb[i] = static_cast<float>(i < C ? p.ba[i] : p.b1[i - C]);
+        for (int i = tid; i < L::CP + CI; i += NTHREADS) lb[i] = i < C ? static_cast<float>(p.ba[i]) : i < L::CP ? 0.f : static_cast<float>(p.b1[i - L::CP]);
     }
     const float* const lba = reinterpret_cast<const float*>(smem + OFF_BIAS);
-    const float* const lb1 = lba + C;
+    const float* const lb1 = lba + L::CP;
     unsigned tab = lds_base + OFF_TABLE + (lane & (RT - 1)) * 16;
 
     // ---- weight streams: waves 0 .. 3 first, then 4 .. 7 (their shares may differ); fragment f of a wave at 1 KB f
@@ -214,7 +218,7 @@ __device__ __forceinline__ void pair_body(const PairParams& p, char* const smem)
                         const int ch = cb_c + 32 * j + 16 * pr;
                         *run_b(t, ch) = o;
                         const int m = m0 + 32 * t + pxv;
-                        if (m < p.M) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
+                        if (m < p.M && c_on) store_line(p.y + static_cast<size_t>(m) * p.ldy + ch + 8 * hiv, o);
                     }
         }
         __syncthreads();            // `in` complete in B; every wave is done with the input rows in A

@@ -1,3 +1,9 @@
+import os as _os
+
+# one hardware queue per stream-priority level: the configuration the codec objects are measured in; set here, in
+# front of the first CUDA / HIP call of the test process, so that the plug-in finds it (it warns when the runtime is up without it)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+
 import os
 import sys
 

@@ -588,6 +588,12 @@ def test_dcb_tail_equals_four_launches(ops, H, W, C, CD, CF, use_dw, shortcut, q
     (384, 192, 32640, False, True, False, True, False),
     (384, 192, 12289, False, False, True, True, True),
     (384, 192, 33, True, False, False, True, False),
+    # ... and the intra decoder's last block: block width 192 as well (six tiles of the C-wide layers on six waves, two waves on zeros)
+    (192, 192, 32640, False, False, False, False, False),
+    (192, 192, 32640, True, False, True, True, False),
+    (192, 192, 12289, False, True, False, True, True),
+    (192, 192, 100, False, False, False, False, True),
+    (192, 192, 129600, False, False, False, False, False),
 ])
 def test_dcb_nsplit_equals_launch_sequence(ops, C, CI, P, shortcut, quant, q2, nxt, inplace):
     """The same block through kernels/dcb_nsplit.hip (round 3: activations in LDS, every wave streams its quarter of
@@ -746,6 +752,9 @@ def test_dcb_nsplit_closing_conv_equals_launch_sequence(ops, C, CI, NN, P, short
     (192, 512, 512, 32640),    # HT-L: feature_adaptor_i.conv.0
     (192, 512, 256, 32640),    # HT-S: feature_adaptor_i.conv.0
     (192, 512, 256, 45),
+    (384, 192, 192, 32640),    # intra: dec.dec_2 (block width 192: two of the eight waves walk zeros)
+    (384, 192, 192, 12801),
+    (384, 192, 192, 70),
 ])
 def test_dcb_pair_equals_two_launches(ops, CIN, C, CI, P):
     """Round 6: a block's adaptor and its dc.0 in ONE launch (kernels/dcb_pair8_kernel.h: the adaptor output stays in LDS as
