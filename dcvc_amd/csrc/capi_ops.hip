@@ -269,6 +269,47 @@ int dcvc_dcb_nsplit_fin(const void* t2, int ldt, const void* x, int ldx, const v
     });
 }
 
+int dcvc_dcb_nsplit_dw_supported(int c, int ci, int pixels)
+{
+    return dcvc::dcb_nsplit_dw_supported(c, ci, pixels) ? 1 : 0;
+}
+
+int dcvc_dcb_nsplit_dw(const void* t1, int ldt, const void* wdw, int width, const void* x, int ldx, const void* w3, const void* b3,
+                       const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                       const void* w1n, const void* b1n, void* t1n, int ldt1,
+                       const void* wfin, const void* bfin, const void* qfin, void* yfin, int ldyfin, int nfin,
+                       void* y, int ldy, int pixels, int c, int ci, int shortcut, void* stream)
+{
+    return dcvc::guarded([&] {
+        dcvc::kernels_init();
+        nsplit_check_shape(c, ci);
+        if (!t1 || !wdw || !w3 || !w0 || !w2) throw std::invalid_argument("dcb_nsplit_dw: missing operand");
+        if (!dcvc::dcb_nsplit_dw_supported(c, ci, pixels)) throw std::invalid_argument("dcb_nsplit_dw: no kernel variant with the depthwise conv inside for this block shape");
+        if (wfin != nullptr && !dcvc::dcb_nsplit_fin_supported(c, ci, nfin)) throw std::invalid_argument("dcb_nsplit_dw: no kernel variant for this closing conv");
+        hipStream_t st = S(stream);
+        const AsyncBuf wmain(dcvc::dcb_nsplit_main_halves(c, ci) * 2, st);
+        dcvc::dcb_nsplit_pack_main(H(w3), H(w0), H(w2), c, ci, wmain.half(), st);
+        std::unique_ptr<AsyncBuf> wnext, wf;
+        if (w1n != nullptr) {
+            wnext = std::make_unique<AsyncBuf>(dcvc::dcb_nsplit_dc0_halves(c, ci) * 2, st);
+            dcvc::dcb_nsplit_pack_dc0(H(w1n), c, ci, wnext->half(), st);
+        }
+        if (wfin != nullptr) {
+            wf = std::make_unique<AsyncBuf>(dcvc::dcb_nsplit_fin_halves(c, nfin) * 2, st);
+            dcvc::dcb_nsplit_pack_fin(H(wfin), c, nfin, wf->half(), st);
+        }
+        dcvc::DcbNsplitDesc d;
+        d.t1 = H(t1); d.ldt = ldt; d.wdw = H(wdw); d.width = width; d.x = H(x); d.ldx = ldx;
+        d.wmain = wmain.half();
+        d.wnext = wnext ? wnext->half() : nullptr;
+        d.b3 = H(b3); d.b0 = H(b0); d.b2 = H(b2); d.b1n = H(b1n); d.q = H(q); d.q2 = H(q2);
+        d.t1n = H(t1n); d.ldt1 = ldt1; d.y = H(y); d.ldy = ldy;
+        d.pixels = pixels; d.c = c; d.ci = ci; d.shortcut = shortcut != 0;
+        if (wf) { d.wfin = wf->half(); d.bfin = H(bfin); d.qfin = H(qfin); d.yfin = H(yfin); d.ldyfin = ldyfin; d.nfin = nfin; }
+        dcvc::dcb_nsplit(d, st);
+    });
+}
+
 int dcvc_dcb_nsplit_pack(const void* w3, const void* w0, const void* w2, const void* w1n, int c, int ci, void* stream, void** handle)
 {
     return dcvc::guarded([&] {

@@ -226,6 +226,8 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         throw std::runtime_error("DepthConvBlock: scratch planes too small");
     }
     View in = x;
+    half_t* const p1 = s.hand != 0 ? s.t2 : s.t1;      // dc.0's output (ours, or handed over by the previous launch)
+    half_t* const p2 = s.hand != 0 ? s.t1 : s.t2;      // the depthwise conv's output / the next block's dc.0 output
     if (has_adaptor && shortcut) {
         // the adaptor output would have to survive the in-place dc.3 / ffn.2 updates
         throw std::invalid_argument("DepthConvBlock with adaptor and shortcut is not a DCVC-UF block");
@@ -241,7 +243,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
             // adaptor + dc.0 in ONE launch (kernels/dcb_pair8_kernel.h): the adaptor output stays in LDS as dc.0's operand
             DcbPairDesc d;
             d.x = x.p; d.ldx = x.ld; d.wa = packed_adaptor; d.ba = adaptor.b; d.w1 = packed_dc0; d.b1 = dc0.b;
-            d.y = a.p; d.ldy = a.ld; d.t1 = s.t1; d.ldt1 = cdc; d.pixels = P; d.cin = adaptor.cin; d.c = c; d.ci = cdc;
+            d.y = a.p; d.ldy = a.ld; d.t1 = p1; d.ldt1 = cdc; d.pixels = P; d.cin = adaptor.cin; d.c = c; d.ci = cdc;
             dcb_pair(d, st);
             dc0_done = true;
         } else {
@@ -258,14 +260,14 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
     if (!tail_dc0 && !dc0_done) {   // dc.0 + WSiLU
         Conv1x1Desc d;
         d.x = in.p; d.ldx = in.ld; d.w = dc0.w; d.bias = dc0.b; d.wsilu = true;
-        d.y = s.t1; d.ldy = cdc; d.pixels = P; d.cin = c; d.cout = cdc;
+        d.y = p1; d.ldy = cdc; d.pixels = P; d.cin = c; d.cout = cdc;
         conv1x1(d, st);
     }
     if (tail) {
         // [dc.0 +] depthwise + dc.3 + ffn.0 + ffn.2 in one launch (kernels/dcb_tail.hip)
         DcbTailDesc d;
         if (tail_dc0) { d.w1 = dc0.w; d.b1 = dc0.b; }
-        d.t = s.t1; d.ldt = cdc; d.dw = dw; d.x = in.p; d.ldx = in.ld;
+        d.t = p1; d.ldt = cdc; d.dw = dw; d.x = in.p; d.ldx = in.ld;
         d.w3 = dc3.w; d.b3 = dc3.b; d.w0 = ffn0.w; d.b0 = ffn0.b; d.w2 = ffn2.w; d.b2 = ffn2.b;
         d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld;
         d.H = H; d.W = W; d.c = c; d.cdc = cdc; d.cffn = cffn; d.shortcut = shortcut;
@@ -273,15 +275,21 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         if (fin != nullptr) run_fin(*fin, y, P, st);
         return;
     }
-    dwconv3x3(s.t1, cdc, dw, s.t2, cdc, H, W, cdc, st);
+    // the narrow blocks take their depthwise conv into the block launch (dcb_nsplit8_kernel.h, DW): dc.0's output is read from one
+    // scratch plane, the next block's written to the other
+    const bool dw_inside = nsplit() && dcb_nsplit_dw_supported(c, cdc, P);
+    if (!dw_inside) dwconv3x3(p1, cdc, dw, p2, cdc, H, W, cdc, st);
     if (nsplit()) {
-        // dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) in one launch, activations in LDS, weights per wave from L2
+        // [depthwise +] dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) in one launch, activations in LDS, weights per wave from L2
         DcbNsplitDesc d;
-        d.t2 = s.t2; d.ldt = cdc; d.x = in.p; d.ldx = in.ld;
+        d.ldt = cdc; d.x = in.p; d.ldx = in.ld;
+        if (dw_inside) { d.t1 = p1; d.wdw = dw; d.width = W; }
+        else d.t2 = p2;
         d.wmain = packed_main; d.b3 = dc3.b; d.b0 = ffn0.b; d.b2 = ffn2.b;
         d.q = q_fused; d.q2 = q_after; d.y = y.p; d.ldy = y.ld; d.pixels = P; d.c = c; d.ci = cdc; d.shortcut = shortcut;
         if (next != nullptr) {
-            d.wnext = next->packed_dc0; d.b1n = next->dc0.b; d.t1n = s.t1; d.ldt1 = next->cdc;
+            d.wnext = next->packed_dc0; d.b1n = next->dc0.b; d.t1n = dw_inside ? p2 : p1; d.ldt1 = next->cdc;
+            if (dw_inside) s.hand ^= 1;
         }
         const bool fin_inside = fin != nullptr && fin->w->packed != nullptr && dcb_nsplit_fin_supported(c, cdc, fin->w->conv.cout);
         if (fin_inside) {
@@ -295,7 +303,7 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
     }
     {   // dc.3 (+ folded depthwise bias) + shortcut
         Conv1x1Desc d;
-        d.x = s.t2; d.ldx = cdc; d.w = dc3.w; d.bias = dc3.b; d.r1 = in.p; d.ldr1 = in.ld;
+        d.x = p2; d.ldx = cdc; d.w = dc3.w; d.bias = dc3.b; d.r1 = in.p; d.ldr1 = in.ld;
         d.y = y.p; d.ldy = y.ld; d.pixels = P; d.cin = cdc; d.cout = c;
         conv1x1(d, st);
     }

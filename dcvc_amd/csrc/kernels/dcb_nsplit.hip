@@ -133,6 +133,24 @@ bool dcb_nsplit_fin_supported(int c, int ci, int nn)
     return false;
 }
 
+// block shapes the kernel is also instantiated for with the block's depthwise conv inside (dcb_nsplit8_256_128_dw.hip: LDS has room
+// for dc.0's output around a tile next to the activations only in the narrow blocks)
+static bool nsplit_wide(int pixels, int c)
+{
+    // 64-pixel workgroups when they fill the chip (picture resolution / 8), 32 otherwise (/ 16: 255 workgroups at 1080p)
+    // (768-wide blocks - the hierarchical models' prior fusion at / 16 - have LDS for 32 pixels only)
+    // DCVC_NSPLIT_PX=32: 32-pixel workgroups everywhere (A/B: twice the tiles per workgroup, half the work per weight byte)
+    static const bool narrow_all = [] { const char* e = getenv("DCVC_NSPLIT_PX"); return e != nullptr && atoi(e) == 32; }();
+    return pixels >= 64 * 200 && c < 768 && !narrow_all;
+}
+
+bool dcb_nsplit_dw_supported(int c, int ci, int pixels)
+{
+    static const bool off = [] { const char* e = getenv("DCVC_NSPLIT_DW"); return e != nullptr && atoi(e) == 0; }();   // A/B: the depthwise conv as a launch of its own
+    if (off || pixels <= 0) return false;
+    return (c == 256 && ci == 128) || (c == 384 && ci == 192 && !nsplit_wide(pixels, c));
+}
+
 void dcb_nsplit_timeline_buffer(long long* device_buffer)
 {
     g_ns_timeline = device_buffer;
@@ -216,7 +234,13 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     if ((d.ldt % 8) || (d.ldx % 8) || (d.ldy % 8) || (d.wnext && d.ldt1 % 8)) {
         throw std::invalid_argument("dcb_nsplit: leading dimensions must be multiples of 8 channels");
     }
-    if (!d.t2 || !d.x || !d.wmain || !d.b3 || !d.b0 || !d.b2 || (!d.y && !d.wfin) || (d.wnext && (!d.b1n || !d.t1n))) {
+    if (d.t1 != nullptr) {
+        if (d.t2 != nullptr) throw std::invalid_argument("dcb_nsplit: either the depthwise conv's output (t2) or its input (t1)");
+        if (!dcb_nsplit_dw_supported(d.c, d.ci, d.pixels)) throw std::invalid_argument("dcb_nsplit: no kernel with the depthwise conv inside for this block shape and size");
+        if (!d.wdw || d.width <= 0 || d.pixels % d.width != 0) throw std::invalid_argument("dcb_nsplit: depthwise conv inside needs its taps and the picture's width");
+        if (d.t1 == d.t1n) throw std::invalid_argument("dcb_nsplit: dc.0's output for the next block must not overwrite this block's (neighbouring workgroups read it)");
+    }
+    if ((!d.t2 && !d.t1) || !d.x || !d.wmain || !d.b3 || !d.b0 || !d.b2 || (!d.y && !d.wfin) || (d.wnext && (!d.b1n || !d.t1n))) {
         throw std::invalid_argument("dcb_nsplit: missing operand");
     }
     if (d.wfin != nullptr) {
@@ -226,6 +250,7 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     }
     NsParams p{};
     p.t2 = d.t2; p.ldt = d.ldt; p.x = d.x; p.ldx = d.ldx;
+    p.t1 = d.t1; p.wdw = d.wdw; p.W = d.width;
     p.wmain = reinterpret_cast<const half8*>(d.wmain); p.wnext = reinterpret_cast<const half8*>(d.wnext);
     p.b3 = d.b3; p.b0 = d.b0; p.b2 = d.b2; p.b1n = d.b1n; p.q = d.q; p.q2 = d.q2;
     p.wsilu = wsilu_table_device();
@@ -234,13 +259,11 @@ void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
     if (d.wfin != nullptr) {      // the NEXT slot holds the chain's closing conv
         p.wnext = reinterpret_cast<const half8*>(d.wfin); p.b1n = d.bfin; p.qf = d.qfin; p.t1n = d.yfin; p.ldt1 = d.ldyfin;
     }
-    // 64-pixel workgroups when they fill the chip (picture resolution / 8), 32 otherwise (/ 16: 255 workgroups at 1080p)
-    // (768-wide blocks - the hierarchical models' prior fusion at / 16 - have LDS for 32 pixels only)
-    // DCVC_NSPLIT_PX=32: 32-pixel workgroups everywhere (A/B: twice the tiles per workgroup, half the work per weight byte)
-    static const bool narrow_all = [] { const char* e = getenv("DCVC_NSPLIT_PX"); return e != nullptr && atoi(e) == 32; }();
-    const bool wide = d.pixels >= 64 * 200 && d.c < 768 && !narrow_all;
+    const bool wide = nsplit_wide(d.pixels, d.c);
     const int next = d.wfin != nullptr ? d.nfin : d.wnext != nullptr ? 1 : 0;
-    if (d.c == 192) nsplit8::run_192_192(p, wide, next, stream);
+    if (d.t1 != nullptr && d.c == 384) nsplit8::run_384_192_dw(p, next, stream);
+    else if (d.t1 != nullptr) nsplit8::run_256_128_dw(p, wide, next, stream);
+    else if (d.c == 192) nsplit8::run_192_192(p, wide, next, stream);
     else if (d.c == 384 && d.ci == 192) nsplit8::run_384_192(p, wide, next, stream);
     else if (d.c == 384) nsplit8::run_384_384(p, wide, next, stream);
     else if (d.c == 768) nsplit8::run_768_768(p, wide, next, stream);

@@ -75,7 +75,7 @@ constexpr int GB = NS8_GATHERS;          // table gathers in flight in the WSiLU
 #ifndef NS8_TRIPLE
 #define NS8_TRIPLE 1
 #endif
-template <int C, int CI, int PXT, int NEXT = 1>
+template <int C, int CI, int PXT, int NEXT = 1, int DW = 0>
 struct Lay {
     // LDS rows are swizzled in groups of 16 chunks (256 bytes): an inner width of 192 (the LD model's (384, 192) prior
     // fusion blocks) lives in rows of 256 channels, a third of them never read
@@ -94,8 +94,29 @@ struct Lay {
     static constexpr int OFF_TABLE = TRIPLE ? 2 * BUF_A + BUF_B : align16k(BUF_A + BUF_B);
     static constexpr int OFF_BIAS = OFF_TABLE + RT * TABLE_BYTES;
     static constexpr int OFF_Q = OFF_BIAS + BIAS_FLOATS * 4;
-    static constexpr int BYTES = OFF_Q + 2 * C * 2;
+    // DW (round 6): the block's depthwise conv inside the launch. dc.0's output arrives as THREE runs of RH consecutive pixel rows
+    // (the tile's pixels - 1 .. + 32 PXT of the picture rows above, at and below: pixels are row-major, a tile is a run of them) by
+    // LDS-DMA into H, lane-linear; the nine taps [9][CI] and a line of zeros (the taps outside the picture) sit in front of it.
+    // The conv of a tile is the work of NW = 8 or 4 waves, each with its own 32 PXT / NW pixels and ITS OWN pieces of H (whole
+    // 1 KB DMA pieces from its first row on: the rows two neighbours both need are fetched twice): no wave waits for another's.
+    static constexpr int run_chunks(int nw)
+    {
+        const int pxw = 32 * PXT / nw, pcs = ((pxw + 2) * (CI / 8) + 63) / 64;       // a wave's pixels, its DMA pieces per run
+        return (nw - 1) * pxw * (CI / 8) + pcs * 64;
+    }
+    static constexpr int rows_per_run()
+    {
+        const int ch = run_chunks(8) > run_chunks(4) ? run_chunks(8) : run_chunks(4);
+        const int r = (ch + CI / 8 - 1) / (CI / 8);
+        return r > 32 * PXT + 2 ? r : 32 * PXT + 2;
+    }
+    static constexpr int RH = rows_per_run();                            // 68 / 36 rows of 128 channels, 36 of 192
+    static constexpr int OFF_WDW = OFF_Q + 2 * C * 2;
+    static constexpr int OFF_ZERO = OFF_WDW + 9 * CI * 2;
+    static constexpr int OFF_H = (OFF_ZERO + 16 + 1023) & ~1023;
+    static constexpr int BYTES = DW != 0 ? OFF_H + 3 * RH * CI * 2 : OFF_Q + 2 * C * 2;
     static_assert(BYTES <= 160 * 1024, "LDS budget");
+    static_assert(DW == 0 || TRIPLE, "depthwise conv inside: needs the second t2 buffer");
 };
 
 // Per-wave tile / fragment counts. A "tile" = 32 output channels; a fragment = one MFMA "A" operand (32 channels x 16 k).
@@ -140,7 +161,7 @@ struct Geo {
     static_assert(C % 64 == 0 && CI % 64 == 0 && 4 * (P0_HI + P0_LO) == PAIRS && P0_LO >= 1, "channel counts the eight waves can share");
 };
 
-template <int C, int CI, int PXT, int NEXT, bool HIW>
+template <int C, int CI, int PXT, int NEXT, int DW, bool HIW>
 __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
 {
     using G = Geo<C, CI>;
@@ -154,11 +175,11 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     constexpr int NT_C = G::nt_c(HIW), NP = G::np(HIW), TP = G::TP;
     constexpr int F_DC3 = G::f_dc3(HIW), F_FFN0 = G::f_ffn0(HIW), F_MAIN = G::f_main(HIW), F_DC0 = G::f_next(NEXT, HIW);
     constexpr int NT_N = G::nt_next(NEXT, HIW);                     // this wave's 32-channel tiles of the NEXT slot
-    constexpr int CIP = Lay<C, CI, PXT, NEXT>::CIP;            // LDS row of the CI-wide tensors (padded to 16-chunk groups)
-    constexpr int CP = Lay<C, CI, PXT, NEXT>::CP;
+    constexpr int CIP = Lay<C, CI, PXT, NEXT, DW>::CIP;            // LDS row of the CI-wide tensors (padded to 16-chunk groups)
+    constexpr int CP = Lay<C, CI, PXT, NEXT, DW>::CP;
     constexpr int CH_C = CP / 8, CH_I = CIP / 8;                // 16-byte chunks per LDS row
     constexpr int PITCH_C = CP * 2, PITCH_I = CIP * 2;
-    using L = Lay<C, CI, PXT, NEXT>;
+    using L = Lay<C, CI, PXT, NEXT, DW>;
     constexpr bool TRIPLE = L::TRIPLE;
     constexpr int RT = L::RT;
     constexpr int OFF_B = L::OFF_B, OFF_A2 = L::OFF_A2;
@@ -226,6 +247,9 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         return *reinterpret_cast<const half8*>(src);
     };
     const half8 cv0 = const_unit(0), cv1 = const_unit(CONST_PER_THREAD > 1 ? 1 : 0);
+    static_assert(DW == 0 || 9 * CI / 8 <= NTHREADS, "the depthwise taps: one 16-byte unit per thread");
+    half8 wdv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (DW != 0) wdv = *reinterpret_cast<const half8*>(p.wdw + min(tid, 9 * CI / 8 - 1) * 8);
     const float* const lb3 = reinterpret_cast<const float*>(smem + OFF_BIAS);
     const float* const lb0 = lb3 + C;
     const float* const lb2 = lb3 + C + 4 * CI;
@@ -272,6 +296,100 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         }
     };
     using ChI = std::integral_constant<int, CH_I>;
+    // ---- DW: dc.0's output around the pixels of wave `wi` of NW -> H (three runs of RH pixel rows from pixel first_row - 1 of the
+    // picture rows above / at / below; rows clamped to the tensor - what lies outside the picture is never read back)
+    constexpr int RH = L::RH;
+    constexpr int CH_H = CI / 8;                                    // 16-byte chunks per row of H (unpadded, unswizzled)
+    auto dma_halo = [&](auto nw_tag, int wi, int first_row) {
+        constexpr int NW = decltype(nw_tag)::value;
+        constexpr int PXW = PX / NW, PCS = ((PXW + 2) * CH_H + 63) / 64;
+        static_assert((NW - 1) * PXW * CH_H + PCS * 64 <= RH * CH_H, "a wave's pieces stay inside the run");
+#pragma unroll
+        for (int run = 0; run < 3; ++run)
+#pragma unroll
+            for (int i = 0; i < PCS; ++i) {
+                const int pos = wi * (PXW * CH_H) + i * 64 + (tidv & 63);     // chunk of the run
+                const int j = pos / CH_H, pc = pos % CH_H;
+                const int g = min(max(first_row + (run - 1) * p.W - 1 + j, 0), p.M - 1);
+                lds_dma16(p.t1, static_cast<unsigned>(g * p.ldt + pc * 8) * 2u, lds_base + L::OFF_H + (run * (RH * CH_H) + wi * (PXW * CH_H) + i * 64) * 16);
+            }
+    };
+    constexpr int H_PER_WAVE8 = 3 * (((PX / 8 + 2) * CH_H + 63) / 64);      // pieces per wave when all eight share a tile
+    // ---- DW: the depthwise 3x3 conv of a tile, H -> the t2 buffer at `dst` (swizzled as dma_tile leaves it), by NW waves of which
+    // this one is number `wi`: fp32 fmaf chain over the taps (ky, kx) ascending from 0, taps outside the picture read zeros
+    // (dwconv.hip skips them: the same sum - a chain that starts at + 0 never reaches - 0)
+    auto dw_tile = [&](auto nw_tag, int wi, int dst, int first_row) {
+        constexpr int NW = decltype(nw_tag)::value;
+        constexpr int PXW = PX / NW;                                 // this wave's pixels: wi PXW .. + PXW - 1 of the tile
+        constexpr int ITEMS = PXW * CH_H;                            // its (pixel, 8-channel chunk) pairs, 64 per step
+        constexpr int STEPS = (ITEMS + 63) / 64;
+        constexpr bool FIXED_CHUNK = 64 % CH_H == 0;                 // a lane keeps its chunk from step to step: the taps stay in registers
+        half8 wt[9];
+        if constexpr (FIXED_CHUNK) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const half8*>(smem + L::OFF_WDW + (k * CI + (tidv & (CH_H - 1)) * 8) * 2);
+        }
+        // the tile's first pixel in the picture (wave-uniform: scalar registers)
+        const int fr = __builtin_amdgcn_readfirstlane(first_row);
+        const int y0 = fr / p.W, x0 = fr - y0 * p.W;
+        const int n0 = wi * ITEMS;                                   // H is [3][RH][CH_H] chunks: tap (ky, kx) of item n at chunk n0 + n + (ky RH + kx) CH_H
+        // the nine taps of step i's item into registers
+        auto taps = [&](int i, half8 (&v)[9]) {
+            const int n = i * 64 + (tidv & 63);
+            const int base = L::OFF_H + (n0 + n) * 16;
+            // the step's pixels r_lo .. r_hi of the tile (scalar): all of them inside the picture with all their neighbours?
+            const int r_lo = wi * PXW + i * 64 / CH_H, r_hi = wi * PXW + (i * 64 + 63) / CH_H;
+            int xf = x0 + r_lo, yf = y0;
+            while (xf >= p.W) { xf -= p.W; ++yf; }
+            const bool inner = yf > 0 && fr + r_hi + p.W < p.M && xf >= 1 && xf + (r_hi - r_lo) + 1 < p.W;
+            if (inner) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) v[k] = *reinterpret_cast<const half8*>(smem + base + ((k / 3) * RH + k % 3) * CH_H * 16);
+            } else {
+                const int r = wi * PXW + n / CH_H;
+                const int m = first_row + r;
+                int xx = xf + (r - r_lo), yy = yf;
+                while (xx >= p.W) { xx -= p.W; ++yy; }
+                const bool up = yy > 0, down = m + p.W < p.M, left = xx > 0, right = xx + 1 < p.W;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int ky = k / 3, kx = k % 3;
+                    const bool ok = (ky != 0 || up) && (ky != 2 || down) && (kx != 0 || left) && (kx != 2 || right);
+                    v[k] = *reinterpret_cast<const half8*>(smem + (ok ? base + (ky * RH + kx) * CH_H * 16 : L::OFF_ZERO));
+                }
+            }
+        };
+        // (the taps of step i + 1 are read while step i's chain runs: a read-use pair per tap, as the compiler lays the loop out by
+        // itself, exposes the LDS latency nine times per item)
+        half8 v[2][9];
+        taps(0, v[0]);
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            if (i + 1 < STEPS) taps(i + 1, v[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int n = i * 64 + (tidv & 63);
+            const int r = wi * PXW + n / CH_H, pc = n % CH_H;        // pixel of the tile, chunk of its row
+            if constexpr (!FIXED_CHUNK) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const half8*>(smem + L::OFF_WDW + (k * CI + pc * 8) * 2);
+            }
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(static_cast<float>(v[i & 1][k][e]), static_cast<float>(wt[k][e]), acc[e]);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = to_half(acc[e]);
+            if (ITEMS % 64 == 0 || n < ITEMS) *reinterpret_cast<half8*>(smem + dst + r * PITCH_I + ((pc ^ (r & 15)) << 4)) = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // (where the waves of a SIMD pair run different bodies, the depthwise conv of the NEXT tile is the work of the waves 4 .. 7: their
+    // share of the NEXT slot is the smaller one - none at all for dc.0 of a (256, 128) block)
+    constexpr bool DW_ALL = G::even(NEXT);
     // ---- the block input x of a tile (dc.3's residual) waits in registers, in the layout of dc.3's epilogue
     half8 xr[NT_C > 0 ? NT_C : 1][PXT][2];
     int pxv = px, hiv = hi;
@@ -286,13 +404,14 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         }
     };
     // first tile: t2 -> A, the first weight fragments, x; then the constants go to LDS
-    dma_tile(ChI{}, p.t2, p.ldt, 0, m0);
+    if constexpr (DW != 0) dma_halo(std::integral_constant<int, 8>{}, wave, m0);
+    else dma_tile(ChI{}, p.t2, p.ldt, 0, m0);
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, RING>([&](auto i) { issue(i); });
     __builtin_amdgcn_sched_barrier(0);
     load_x(m0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX * CH_I / NTHREADS + RING + NT_C * PXT * 2) : "memory");     // the constants have arrived
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW != 0 ? H_PER_WAVE8 : PX * CH_I / NTHREADS) + RING + NT_C * PXT * 2) : "memory");     // the constants have arrived
     {
         float4* t = reinterpret_cast<float4*>(smem + OFF_TABLE);
         if (RT == 4 || tid < WSILU_SEGMENTS) t[tid] = tab0;
@@ -316,10 +435,19 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         };
         put(0, cv0);
         if (CONST_PER_THREAD > 1) put(1, cv1);
+        if constexpr (DW != 0) {
+            if (tid < 9 * CI / 8) *reinterpret_cast<half8*>(smem + L::OFF_WDW + tid * 16) = wdv;
+            if (tid == NTHREADS - 1) *reinterpret_cast<half8*>(smem + L::OFF_ZERO) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
     }
     // this wave's pieces of t2 have landed (x, requested last, may still be on its way: dc.3's epilogue is its first use)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT_C * PXT * 2) : "memory");
     __syncthreads();
+    if constexpr (DW != 0) {
+        // the first tile's depthwise conv: all eight waves, H -> A
+        dw_tile(std::integral_constant<int, 8>{}, wave, 0, m0);
+        __syncthreads();
+    }
     stamp();
 
     // ---- fragment addressing. Row of pixel tile t: (32 t + px) * pitch; chunk c of a row sits at c ^ (px & 15).
@@ -442,7 +570,17 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
             if constexpr (TRIPLE && pass == NP - 1) {
                 // the next tile's t2 into the OTHER buffer and its x into registers, in front of an epilogue that needs no
                 // weights (the ring already holds ffn.2's first fragments: they return before these transfers)
-                if (has_next) dma_tile(ChI{}, p.t2, p.ldt, abuf == 0 ? OFF_A2 : 0, next_tile * PX);
+                if constexpr (DW != 0) {
+                    // (H is free: this tile's depthwise conv ran during the previous tile. Where the waves 4 .. 7 do the conv, they alone
+                    // fetch: behind these transfers a wave's weight fragments would wait - loads return in order - and the waves 0 .. 3
+                    // have the NEXT slot's still to come)
+                    if (has_next) {
+                        if constexpr (DW_ALL) dma_halo(std::integral_constant<int, 8>{}, wave, next_tile * PX);
+                        else if constexpr (!HIW) dma_halo(std::integral_constant<int, 4>{}, wave - 4, next_tile * PX);
+                    }
+                } else {
+                    if (has_next) dma_tile(ChI{}, p.t2, p.ldt, abuf == 0 ? OFF_A2 : 0, next_tile * PX);
+                }
                 if constexpr (NT_C > 0) load_x(next_tile * PX);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -545,7 +683,6 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     }
     if constexpr (NEXT != 0) __syncthreads();       // y complete in B
     stamp();
-
     // ================================================================ the NEXT slot   (B -> memory)
     //   NEXT = 1: dc.0 of the next block, t1' = WSiLU(W1' y + b1');  NEXT = NN: the chain's closing conv, o = (Wf y + bf) [* qf]
     if constexpr (NEXT != 0 && NT_N > 0) {
@@ -609,6 +746,16 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         }
         stamp();
     }
+    if constexpr (DW != 0) {
+        // the NEXT tile's depthwise conv, H -> the other t2 buffer: beside the NEXT slot (the waves 4 .. 7, whose share of it is the
+        // smaller one - none at all for dc.0 of a (256, 128) block) or behind it (all waves). A wave reads only the pieces of H it
+        // fetched itself: it waits for those (the ring's fragments of the next tile, requested later, may stay on their way)
+        if (has_next) {
+            if constexpr (DW_ALL || !HIW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING) : "memory");
+            if constexpr (DW_ALL) dw_tile(std::integral_constant<int, 8>{}, wave, abuf == 0 ? OFF_A2 : 0, next_tile * PX);
+            else if constexpr (!HIW) dw_tile(std::integral_constant<int, 4>{}, wave - 4, abuf == 0 ? OFF_A2 : 0, next_tile * PX);
+        }
+    }
     stamp();
     if (!has_next) break;
     // the next tile's t2 has landed (every wave waits for its own pieces, the barrier covers the others'); every wave is
@@ -636,28 +783,29 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
 #ifndef NS8_OCC2
 #define NS8_OCC2 0
 #endif
-template <int C, int CI, int PXT, int NEXT>
-constexpr int waves_per_simd() { return (NS8_OCC2 != 0 && PXT == 1 && Lay<C, CI, PXT, NEXT>::BYTES <= 80 * 1024) ? 4 : 2; }
+template <int C, int CI, int PXT, int NEXT, int DW = 0>
+constexpr int waves_per_simd() { return (NS8_OCC2 != 0 && PXT == 1 && Lay<C, CI, PXT, NEXT, DW>::BYTES <= 80 * 1024) ? 4 : 2; }
 
-template <int C, int CI, int PXT, int NEXT>
-__global__ void __launch_bounds__(NTHREADS, (waves_per_simd<C, CI, PXT, NEXT>()))
+// DW = 1: the block's depthwise conv inside (p.t1 / p.wdw / p.W instead of p.t2)
+template <int C, int CI, int PXT, int NEXT, int DW = 0>
+__global__ void __launch_bounds__(NTHREADS, (waves_per_simd<C, CI, PXT, NEXT, DW>()))
 dcb_nsplit8_kernel(const NsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem8[];
     if constexpr (Geo<C, CI>::even(NEXT)) {
-        block_body<C, CI, PXT, NEXT, true>(p, smem8);
+        block_body<C, CI, PXT, NEXT, DW, true>(p, smem8);
     } else {
         // the waves of a SIMD pair own different numbers of tiles: two bodies, one barrier sequence
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) block_body<C, CI, PXT, NEXT, true>(p, smem8);
-        else block_body<C, CI, PXT, NEXT, false>(p, smem8);
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) block_body<C, CI, PXT, NEXT, DW, true>(p, smem8);
+        else block_body<C, CI, PXT, NEXT, DW, false>(p, smem8);
     }
 }
 
-template <int C, int CI, int PXT, int NEXT>
+template <int C, int CI, int PXT, int NEXT, int DW = 0>
 void launch8(const NsParams& p, hipStream_t stream)
 {
-    auto kern = dcb_nsplit8_kernel<C, CI, PXT, NEXT>;
-    constexpr int smem = Lay<C, CI, PXT, NEXT>::BYTES;
+    auto kern = dcb_nsplit8_kernel<C, CI, PXT, NEXT, DW>;
+    constexpr int smem = Lay<C, CI, PXT, NEXT, DW>::BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
     constexpr int MAX_DEVICES = 64;
     static std::once_flag once[MAX_DEVICES];
@@ -677,13 +825,14 @@ void launch8(const NsParams& p, hipStream_t stream)
         hip_check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
         cu_count[dev] = n > 0 ? n : 256;
     });
-    const int cus = cu_count[dev] * (waves_per_simd<C, CI, PXT, NEXT>() / 2);     // persistent workgroups the chip holds at once
+    const int cus = cu_count[dev] * (waves_per_simd<C, CI, PXT, NEXT, DW>() / 2);     // persistent workgroups the chip holds at once
     const int tiles = (p.M + 32 * PXT - 1) / (32 * PXT);
     const int grid = tiles < cus ? tiles : cus;
     hipEvent_t ev0, ev1;
     const int kflop = 6 * CI + (NEXT == 1 ? CI : NEXT);      // 2 M C kflop = the launch's FLOPs (closing conv: + 2 M C NN)
-    // (variant: family 5 | inner width | what the NEXT slot holds (0, 1 = dc.0, NN = a closing conv's width) << 12)
-    if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x50000000 | CI | (NEXT << 12), 0.f}, &ev0, &ev1)) {
+    // (variant: family 5 | inner width | what the NEXT slot holds (0, 1 = dc.0, NN = a closing conv's width) << 12 | depthwise conv inside << 24;
+    // the depthwise conv's 18 CI flops per pixel are not counted)
+    if (gemm_profile_slot(GemmLaunchInfo{p.M, C, kflop, 0x50000000 | CI | (NEXT << 12) | (DW << 24), 0.f}, &ev0, &ev1)) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, ev0, ev1, 0, p);
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), smem, stream, p);
@@ -701,6 +850,16 @@ void run_px8(const NsParams& p, int next, hipStream_t stream)
     if (!hit) throw std::invalid_argument("dcb_nsplit8: no instantiation for a closing conv of width " + std::to_string(next));
 }
 
+// the same with the block's depthwise conv inside the launch (DW = 1)
+template <int C, int CI, int PXT, int... FINS>
+void run_px8_dw(const NsParams& p, int next, hipStream_t stream)
+{
+    if (next == 0) { launch8<C, CI, PXT, 0, 1>(p, stream); return; }
+    if (next == 1) { launch8<C, CI, PXT, 1, 1>(p, stream); return; }
+    const bool hit = ((next == FINS ? (launch8<C, CI, PXT, FINS, 1>(p, stream), true) : false) || ... || false);
+    if (!hit) throw std::invalid_argument("dcb_nsplit8: no instantiation for a closing conv of width " + std::to_string(next));
+}
+
 template <int C, int CI, int... FINS>
 void run_shape8(const NsParams& p, bool wide, int next, hipStream_t stream)
 {
@@ -712,6 +871,8 @@ void run_shape8(const NsParams& p, bool wide, int next, hipStream_t stream)
 
 // dcb_nsplit8_<shape>.hip
 void run_256_128(const NsParams& p, bool wide, int next, hipStream_t stream);
+void run_256_128_dw(const NsParams& p, bool wide, int next, hipStream_t stream);      // depthwise conv inside: dcb_nsplit8_256_128_dw.hip
+void run_384_192_dw(const NsParams& p, int next, hipStream_t stream);                 // ... 32-pixel workgroups only: dcb_nsplit8_384_192_dw.hip
 void run_256_256(const NsParams& p, bool wide, int next, hipStream_t stream);
 void run_192_192(const NsParams& p, bool wide, int next, hipStream_t stream);
 void run_384_192(const NsParams& p, bool wide, int next, hipStream_t stream);

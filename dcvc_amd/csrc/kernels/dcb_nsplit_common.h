@@ -40,6 +40,8 @@ __device__ __forceinline__ void static_for(F&& f)
 
 struct NsParams {
     const half_t* t2; int ldt;
+    // 8-wave kernel with the depthwise conv inside (DW = 1): dc.0's output [M][ldt] instead of t2, the taps [9][CI], the picture's width
+    const half_t* t1; const half_t* wdw; int W;
     const half_t* x; int ldx;
     const half8* wmain;       // packed dc.3 | ffn.0 | ffn.2: per-wave streams of MFMA "A" fragments (dcb_nsplit.hip pack_main8)
     const half8* wnext;       // packed NEXT slot (dc.0 of the next block / the closing conv) or null

@@ -89,7 +89,13 @@ struct DcbNsplitDesc {
     // block's own output then never leaves LDS (nothing else reads it in the codecs).
     const half_t* wfin = nullptr; const half_t* bfin = nullptr; const half_t* qfin = nullptr;
     half_t* yfin = nullptr; int ldyfin = 0; int nfin = 0;
+    // round 6: the block's depthwise conv inside the launch (dcb_nsplit_dw_supported shapes): t1 = dc.0's output [pixels][ldt]
+    // INSTEAD of t2, wdw = the taps [9][ci] (tap major, as dwconv3x3 takes them), width = the picture's width (pixels = rows x width).
+    // Bit-identical to dwconv3x3 + the launch on its output. t1 must not be the buffer t1n is written to (a workgroup reads its
+    // neighbours' rows of t1).
+    const half_t* t1 = nullptr; const half_t* wdw = nullptr; int width = 0;
 };
+bool dcb_nsplit_dw_supported(int c, int ci, int pixels);      // (256, 128); (384, 192) on 32-pixel workgroups. DCVC_NSPLIT_DW=0: never (A/B)
 int dcb_nsplit_waves();                                      // 8
 bool dcb_nsplit_shape(int c, int ci);                         // a shape the kernel is instantiated for
 bool dcb_nsplit_supported(int c, int cdc, int cffn);          // DCVC_NSPLIT: 0 = off, 1 = full-width blocks only (A/B)

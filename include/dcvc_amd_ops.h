@@ -98,6 +98,19 @@ int dcvc_dcb_nsplit_fin(const void* t2, int ldt, const void* x, int ldx, const v
                         const void* wfin, const void* bfin, const void* qfin, void* yfin, int ldyfin, int nfin,
                         void* y, int ldy, int pixels, int c, int ci, int shortcut, void* stream);
 int dcvc_dcb_nsplit_fin_supported(int c, int ci, int nfin);
+/* The same block WITH its depthwise 3x3 conv inside the launch (round 6; the reference launches d3x3 between dc.0 and dc.3,
+ * layers_proxy.cpp:80-84, cutlass/d3x3.cu:443-446): t1 [pixels][ldt] = dc.0's output (what dcvc_dwconv3x3 would read), wdw = the
+ * taps [9][ci] (tap major, as dcvc_dwconv3x3 takes them), width = the picture's width (pixels = rows x width, row-major). Behind
+ * ffn.2 either dc.0 of the next block (w1n / b1n / t1n; t1n must not be t1) or a chain's closing conv (wfin ... nfin) or neither.
+ * Returns an error for a (c, ci, pixels) the kernel has no such variant of (dcvc_dcb_nsplit_dw_supported: (256, 128); (384, 192) below
+ * 12 800 pixels, where the workgroups take 32 pixels and LDS has room for the rows around them). Bit-identical to
+ * dcvc_dwconv3x3 followed by dcvc_dcb_nsplit / dcvc_dcb_nsplit_fin. */
+int dcvc_dcb_nsplit_dw(const void* t1, int ldt, const void* wdw, int width, const void* x, int ldx, const void* w3, const void* b3,
+                       const void* w0, const void* b0, const void* w2, const void* b2, const void* q, const void* q2,
+                       const void* w1n, const void* b1n, void* t1n, int ldt1,
+                       const void* wfin, const void* bfin, const void* qfin, void* yfin, int ldyfin, int nfin,
+                       void* y, int ldy, int pixels, int c, int ci, int shortcut, void* stream);
+int dcvc_dcb_nsplit_dw_supported(int c, int ci, int pixels);
 
 /* The two 1x1 convs in FRONT of a block's depthwise conv in one launch (round 6; the reference launches conv1x1_bias for the
  * adaptor, layers_proxy.cpp:73-77, then conv1x1_bias_wsilu for dc.0, :79):

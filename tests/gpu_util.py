@@ -47,6 +47,9 @@ class Ops:
         self.dcb_nsplit_fin = _f("dcvc_dcb_nsplit_fin", [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci,
                                                          vp, ci, ci, ci, ci, ci, vp])
         self.dcb_nsplit_fin_supported = _f("dcvc_dcb_nsplit_fin_supported", [ci, ci, ci])
+        self.dcb_nsplit_dw = _f("dcvc_dcb_nsplit_dw", [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci,
+                                                       vp, vp, vp, vp, ci, ci, vp, ci, ci, ci, ci, ci, vp])
+        self.dcb_nsplit_dw_supported = _f("dcvc_dcb_nsplit_dw_supported", [ci, ci, ci])
         self.dcb_pair = _f("dcvc_dcb_pair", [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp])
         self.dcb_pair_supported = _f("dcvc_dcb_pair_supported", [ci, ci, ci])
         self.dcb_nsplit_pack = _f("dcvc_dcb_nsplit_pack", [vp, vp, vp, vp, ci, ci, vp, ctypes.POINTER(vp)])

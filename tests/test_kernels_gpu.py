@@ -733,6 +733,119 @@ def test_dcb_nsplit_closing_conv_equals_launch_sequence(ops, C, CI, NN, P, short
         assert torch.equal(yf2, yf), "closing conv without the block's own output"
 
 
+DW_CASES = [
+    (135, 240, True, 0, False, False, False),     # LD at 1920x1080, / 8: 64-pixel workgroups, dc.0 of the next block behind ffn.2
+    (136, 240, True, 0, True, True, False),
+    (135, 241, False, 0, False, False, False),    # ragged last tile, rows that end inside a tile, nothing behind ffn.2
+    (68, 120, True, 0, False, False, False),      # / 16: 32-pixel workgroups
+    (67, 121, False, 0, True, False, False),
+    (68, 120, False, 128, False, False, False),   # y_spatial_prior.conv.2 behind the block
+    (135, 240, False, 256, False, False, True),   # decoder.conv2 with its quant scale
+    (135, 240, False, 192, False, True, False),   # recon_head.head
+    (270, 480, True, 0, False, False, False),     # 3840x2160, / 8: several tiles per workgroup
+    (201, 65, True, 0, False, False, False),      # a picture barely wider than a tile
+    (300, 50, True, 0, False, True, False),       # ... narrower: a tile spans rows
+    (1000, 13, False, 192, False, False, False),  # ... five rows and more
+    (9, 7, True, 0, False, False, False),         # one ragged 32-pixel... two tiles
+    (1, 40, False, 0, False, False, False),       # a single row: no tap above or below
+    (40, 1, True, 0, False, False, False),        # a single column: no tap left or right
+    (3, 3, False, 128, False, False, True),
+]
+DW_CASES = [(256, 128) + c for c in DW_CASES] + [
+    (384, 192, 68, 120, True, 0, False, False, False),     # LD's prior fusion at 1920x1080, / 16 (rows of 24 chunks: 2 2/3 pixels per wave and step)
+    (384, 192, 68, 120, False, 384, False, False, False),  # ... its last block with y_prior_fusion.conv.3 behind it
+    (384, 192, 67, 121, False, 0, True, True, False),
+    (384, 192, 45, 80, True, 0, False, False, False),      # 1280x720
+    (384, 192, 400, 31, True, 0, False, True, False),      # a tile spans rows
+    (384, 192, 1, 33, False, 384, False, False, True),
+    (384, 192, 70, 1, True, 0, False, False, False),
+]
+
+
+@pytest.mark.parametrize("C,CI,H,W,nxt,NN,shortcut,quant,qfin", DW_CASES)
+def test_dcb_nsplit_with_depthwise_inside_equals_launch_sequence(ops, C, CI, H, W, nxt, NN, shortcut, quant, qfin):
+    """Round 6: the (256, 128) / (384, 192) block launch with the block's depthwise 3x3 conv inside (dc.0's output around a tile by LDS-DMA,
+    the conv by the waves that idle in the NEXT slot) == dwconv3x3 followed by the block launch on its output, bit for bit -
+    with dc.0 of the next block, a closing conv or nothing behind ffn.2."""
+    from gpu_util import call, ptr, stream
+    dev = "cuda"
+    P = H * W
+    if not ops.dcb_nsplit_dw_supported(C, CI, P):
+        pytest.skip("DCVC_NSPLIT_DW=0")
+    ldx = C + 64
+    xbuf = _rand((P, ldx), 1.0, 901).to(dev)
+    t1 = _rand((P, CI), 1.0, 902).to(dev)
+    wd = _rand((CI, 1, 3, 3), 0.3, 913).to(dev)
+    wt = wd[:, 0].permute(1, 2, 0).reshape(9, CI).contiguous()
+    w3 = (_rand((C, CI), 1.0, 903) / CI ** 0.5).half().to(dev)
+    b3 = _rand((C,), 0.3, 904).to(dev)
+    w0 = (_rand((4 * CI, C), 1.0, 905) / C ** 0.5).half().to(dev)
+    b0 = _rand((4 * CI,), 0.3, 906).to(dev)
+    w2 = (_rand((C, CI), 1.0, 907) / CI ** 0.5).half().to(dev)
+    b2 = _rand((C,), 0.3, 908).to(dev)
+    w1n = (_rand((CI, C), 1.0, 909) / C ** 0.5).half().to(dev) if nxt else None
+    b1n = _rand((CI,), 0.3, 910).to(dev) if nxt else None
+    wf = (_rand((NN, C), 1.0, 914) / C ** 0.5).half().to(dev) if NN else None
+    bf = _rand((NN,), 0.3, 915).to(dev) if NN else None
+    q = (_rand((C,), 0.2, 911) + 1.0).half().to(dev) if quant else None
+    qf = (_rand((NN,), 0.2, 912) + 1.0).half().to(dev) if qfin else None
+    # the launches the codecs ran until now: depthwise conv, then the block launch on its output
+    t2 = torch.zeros((P, CI), dtype=torch.half, device=dev)
+    call(ops.dwconv3x3, ptr(t1), CI, ptr(wt), ptr(t2), CI, H, W, CI, stream())
+    want = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev)
+    want_n = torch.full((P, CI + 8), 7.0, dtype=torch.half, device=dev)
+    want_f = torch.full((P, NN + 8), 7.0, dtype=torch.half, device=dev)
+    if NN:
+        call(ops.dcb_nsplit_fin, ptr(t2), CI, ptr(xbuf), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), None,
+             ptr(wf), ptr(bf), ptr(qf), ptr(want_f), NN + 8, NN, ptr(want), C + 8, P, C, CI, 1 if shortcut else 0, stream())
+    else:
+        call(ops.dcb_nsplit, ptr(t2), CI, ptr(xbuf), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), None,
+             ptr(w1n), ptr(b1n), ptr(want_n) if nxt else None, CI + 8, ptr(want), C + 8, P, C, CI, 1 if shortcut else 0, stream())
+    torch.cuda.synchronize()
+    from oracle import nn
+    if P <= 40000:
+        assert np.array_equal(t2.cpu().numpy().reshape(H, W, CI), nn.dwconv3x3(t1.cpu().numpy().reshape(H, W, CI), wd.cpu().numpy()))
+    y = torch.full((P, C + 8), 9.0, dtype=torch.half, device=dev)
+    t1n = torch.full((P, CI + 8), 7.0, dtype=torch.half, device=dev)
+    yf = torch.full((P, NN + 8), 7.0, dtype=torch.half, device=dev)
+    for rep in range(2):        # (twice: the second launch finds the first one's leftovers in LDS-sized caches, not in its logic)
+        call(ops.dcb_nsplit_dw, ptr(t1), CI, ptr(wt), W, ptr(xbuf), ldx, ptr(w3), ptr(b3), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(q), None,
+             ptr(w1n), ptr(b1n), ptr(t1n) if nxt else None, CI + 8,
+             ptr(wf), ptr(bf), ptr(qf), ptr(yf) if NN else None, NN + 8, NN,
+             ptr(y), C + 8, P, C, CI, 1 if shortcut else 0, stream())
+        torch.cuda.synchronize()
+        bad = int((y != want).sum())
+        assert bad == 0, "y: %d of %d outputs differ" % (bad, want.numel())
+        if nxt:
+            bad = int((t1n != want_n).sum())
+            assert bad == 0, "next block's dc.0: %d of %d outputs differ" % (bad, want_n.numel())
+        if NN:
+            bad = int((yf != want_f).sum())
+            assert bad == 0, "closing conv: %d of %d outputs differ" % (bad, want_f.numel())
+
+
+def test_dcb_nsplit_with_depthwise_inside_refuses_what_it_cannot_run(ops):
+    from gpu_util import ptr, stream
+    dev = "cuda"
+    if not ops.dcb_nsplit_dw_supported(256, 128, 64):
+        pytest.skip("DCVC_NSPLIT_DW=0")
+    assert ops.dcb_nsplit_dw_supported(384, 384, 8160) == 0
+    assert ops.dcb_nsplit_dw_supported(384, 192, 8160) == 1 and ops.dcb_nsplit_dw_supported(384, 192, 32640) == 0      # 64-pixel workgroups: no room
+    z = torch.zeros((512, 1024), dtype=torch.half, device=dev)      # (large enough for ffn.0's weights: the entry point packs them before the launch is checked)
+    # dc.0's output for the next block into the buffer the launch still reads its own from
+    rc = ops.dcb_nsplit_dw(ptr(z), 128, ptr(z), 8, ptr(z), 256, ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), None, None,
+                           ptr(z), ptr(z), ptr(z), 128, None, None, None, None, 0, 0, ptr(z), 256, 64, 256, 128, 0, stream())
+    assert rc != 0
+    # a width that does not divide the pixel count
+    rc = ops.dcb_nsplit_dw(ptr(z), 128, ptr(z), 7, ptr(z), 256, ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), None, None,
+                           None, None, None, 0, None, None, None, None, 0, 0, ptr(z), 256, 64, 256, 128, 0, stream())
+    assert rc != 0
+    # a block shape without such a variant
+    rc = ops.dcb_nsplit_dw(ptr(z), 256, ptr(z), 8, ptr(z), 256, ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), None, None,
+                           None, None, None, 0, None, None, None, None, 0, 0, ptr(z), 256, 64, 256, 256, 0, stream())
+    assert rc != 0
+
+
 @pytest.mark.parametrize("CIN,C,CI,P", [
     (448, 256, 128, 32640),    # LD: encoder.conv1.0 ([x unshuffled | ctx] -> 256) at / 8
     (448, 256, 128, 77),
