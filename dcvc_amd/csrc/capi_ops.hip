@@ -483,6 +483,14 @@ int dcvc_dcb_nsplit_timeline_buffer(void* device_buffer)
     return dcvc::guarded([&] { dcvc::dcb_nsplit_timeline_buffer(static_cast<long long*>(device_buffer)); });
 }
 
+int dcvc_dcb_nsplit_dw_hook(const void* t1, const void* wdw, int width)
+{
+    return dcvc::guarded([&] {
+        if (t1 != nullptr && (wdw == nullptr || width <= 0)) throw std::invalid_argument("dcb_nsplit_dw_hook: taps and a width");
+        dcvc::dcb_nsplit_dw_hook(H(t1), H(wdw), width);
+    });
+}
+
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream)
 {
     return dcvc::guarded([&] {

@@ -109,6 +109,10 @@ __global__ void pack_fin8_kernel(const half_t* w, int C, int NN, half8* out)
 }
 
 long long* g_ns_timeline = nullptr;
+// tuning aid (tools/probes/core_bench.hip -w): launches of a shape that has the variant run it with the depthwise conv inside, on these operands
+const half_t* g_dw_hook_t1 = nullptr;
+const half_t* g_dw_hook_taps = nullptr;
+int g_dw_hook_width = 0;
 
 }  // namespace
 
@@ -149,6 +153,11 @@ bool dcb_nsplit_dw_supported(int c, int ci, int pixels)
     static const bool off = [] { const char* e = getenv("DCVC_NSPLIT_DW"); return e != nullptr && atoi(e) == 0; }();   // A/B: the depthwise conv as a launch of its own
     if (off || pixels <= 0) return false;
     return (c == 256 && ci == 128) || (c == 384 && ci == 192 && !nsplit_wide(pixels, c));
+}
+
+void dcb_nsplit_dw_hook(const half_t* t1, const half_t* wdw, int width)
+{
+    g_dw_hook_t1 = t1; g_dw_hook_taps = wdw; g_dw_hook_width = width;
 }
 
 void dcb_nsplit_timeline_buffer(long long* device_buffer)
@@ -225,8 +234,12 @@ bool dcb_nsplit_supported(int c, int cdc, int cffn)
     return cdc == c || dcb_nsplit_mode() >= 2;
 }
 
-void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream)
+void dcb_nsplit(const DcbNsplitDesc& desc, hipStream_t stream)
 {
+    DcbNsplitDesc d = desc;
+    if (g_dw_hook_t1 != nullptr && d.t1 == nullptr && dcb_nsplit_dw_supported(d.c, d.ci, d.pixels) && d.pixels % g_dw_hook_width == 0) {
+        d.t2 = nullptr; d.t1 = g_dw_hook_t1; d.wdw = g_dw_hook_taps; d.width = g_dw_hook_width;
+    }
     if (!dcb_nsplit_shape(d.c, d.ci)) {
         throw std::invalid_argument("dcb_nsplit: (block width, inner width) must be (256, 256), (384, 384), (512, 512), (768, 768), (512, 256), (256, 128), (384, 192) or (192, 192)");
     }

@@ -197,7 +197,15 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     const int px = lane & 31;
     const int hi = lane >> 5;
     const int ntiles = (p.M + PX - 1) / PX;
-    int tile = blockIdx.x;                               // persistent: tiles blockIdx.x, + gridDim.x, ...
+    // persistent: tiles blockIdx.x, + gridDim.x, ... With the depthwise conv inside (DW) a tile also reads dc.0's output of the picture
+    // rows above and below it - tiles W / (32 PXT) further up and down: there the tiles go to the workgroups in eight BANDS, one per XCD
+    // (workgroup w runs on XCD w mod 8), so that those rows are in the XCD's own L2 (fetched by a neighbour) instead of in memory
+    const bool banded = DW != 0 && (gridDim.x & 7) == 0 && ntiles >= static_cast<int>(gridDim.x);
+    const int band0 = banded ? static_cast<int>((blockIdx.x & 7) * ntiles) >> 3 : 0;
+    const int band_n = banded ? (static_cast<int>(((blockIdx.x & 7) + 1) * ntiles) >> 3) - band0 : 0;
+    int slot = blockIdx.x >> 3;                          // banded: this tile's place in the band (band_n >= gridDim.x / 8: the first one exists)
+    int tile = banded ? band0 + slot : static_cast<int>(blockIdx.x);
+    bool first_tile = true;
     int m0 = tile * PX;
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)smem));
     if ((lds_base & 16383u) != 0) __builtin_trap();      // dynamic LDS starts at 0 (no static LDS in this kernel)
@@ -222,7 +230,7 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     const long long rt0 = static_cast<long long>(__builtin_amdgcn_s_memrealtime());
     int stamp_no = 0;
     auto stamp = [&]() {
-        if (p.timeline != nullptr && tid == 0 && stamp_no < 29 && tile == static_cast<int>(blockIdx.x)) {
+        if (p.timeline != nullptr && tid == 0 && stamp_no < 29 && first_tile) {
             p.timeline[static_cast<size_t>(blockIdx.x) * 32 + stamp_no] = static_cast<long long>(__builtin_readcyclecounter());
         }
         ++stamp_no;
@@ -304,6 +312,19 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         constexpr int NW = decltype(nw_tag)::value;
         constexpr int PXW = PX / NW, PCS = ((PXW + 2) * CH_H + 63) / 64;
         static_assert((NW - 1) * PXW * CH_H + PCS * 64 <= RH * CH_H, "a wave's pieces stay inside the run");
+        const int r0 = __builtin_amdgcn_readfirstlane(first_row) - 1 + wi * PXW;      // the first row of this wave's pieces of the middle run
+        if (64 % CH_H == 0 && r0 - p.W >= 0 && r0 + p.W + PCS * (64 / CH_H) <= p.M) {
+            // whole rows per piece and none of them clamped: one lane offset, the pieces' addresses in scalar registers
+            const unsigned lane_off = static_cast<unsigned>(((tidv & 63) / CH_H) * p.ldt + ((tidv & 63) % CH_H) * 8) * 2u;
+#pragma unroll
+            for (int run = 0; run < 3; ++run)
+#pragma unroll
+                for (int i = 0; i < PCS; ++i) {
+                    const half_t* const src = p.t1 + static_cast<size_t>(r0 + (run - 1) * p.W + i * (64 / CH_H)) * p.ldt;
+                    lds_dma16(src, lane_off, lds_base + L::OFF_H + (run * (RH * CH_H) + wi * (PXW * CH_H) + i * 64) * 16);
+                }
+            return;
+        }
 #pragma unroll
         for (int run = 0; run < 3; ++run)
 #pragma unroll
@@ -527,8 +548,9 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
         fa8[i] = rowA + ((32 * i) ^ s0);
         fb8[i] = rowB + ((32 * i) ^ s0);
     }
-    const int next_tile = tile + static_cast<int>(gridDim.x);
-    const bool has_next = next_tile < ntiles;
+    const int next_slot = slot + static_cast<int>(gridDim.x >> 3);
+    const int next_tile = banded ? band0 + next_slot : tile + static_cast<int>(gridDim.x);
+    const bool has_next = banded ? next_slot < band_n : next_tile < ntiles;
     // ================================================================ dc.3: y1 = W3 t2 + b3' + x   (A -> B)
     if constexpr (NT_C > 0) {
         float16v acc[NT_C][PXT];
@@ -762,7 +784,10 @@ __device__ __forceinline__ void block_body(const NsParams& p, char* const smem)
     // done with y in B: B is free for the next tile's y1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp();        // (the first tile's last stamp: every wave has arrived - with the depthwise conv inside, the waves 4 .. 7 from theirs)
     tile = next_tile;
+    slot = next_slot;
+    first_tile = false;
     m0 = tile * PX;
     if constexpr (TRIPLE) {
         abuf = abuf == 0 ? OFF_A2 : 0;

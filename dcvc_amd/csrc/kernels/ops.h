@@ -108,6 +108,7 @@ size_t dcb_nsplit_fin_halves(int c, int nn);
 void dcb_nsplit_pack_fin(const half_t* w /* [nn][c] */, int c, int nn, half_t* out, hipStream_t stream);
 void dcb_nsplit(const DcbNsplitDesc& d, hipStream_t stream);
 void dcb_nsplit_timeline_buffer(long long* device_buffer);    // tuning aid: [workgroups][32] shader-clock stamps
+void dcb_nsplit_dw_hook(const half_t* t1, const half_t* wdw, int width);      // tuning aid: dcb_nsplit launches take their depthwise conv inside, on these operands (null: off)
 
 // The two 1x1 convs in front of a block's depthwise conv in one launch (dcb_pair8_kernel.h, round 6):
 //   y = Wa x + ba (the block's adaptor, layers_proxy.cpp:73-77);  t1 = WSiLU(W1 y + b1) (dc.0, :79).

@@ -172,6 +172,9 @@ int dcvc_x_to_yuv420(const void* x_hat, int row_pixels, int H, int W, void* y16,
  * written by wave 0 of every workgroup of the following contraction launches; NULL = off. */
 int dcvc_gemm_timeline_buffer(void* device_buffer);
 int dcvc_dcb_nsplit_timeline_buffer(void* device_buffer);   /* [workgroups][32] stamps of the N-split block kernel */
+/* tuning aid (tools/probes/core_bench.hip -w): while set, dcvc_dcb_nsplit* launches of a shape that has the variant run with their
+ * depthwise conv inside on these operands (t1 [pixels][ci] instead of the call's t2, taps [9][ci], picture width); t1 = NULL: off */
+int dcvc_dcb_nsplit_dw_hook(const void* t1, const void* wdw, int width);
 
 /* def_elementwise.h: round_z_cuda / int8_to_dtype_cuda */
 int dcvc_round_z(const void* z, void* z_hat, void* z_i8, int count, void* stream);

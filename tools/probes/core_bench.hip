@@ -36,6 +36,7 @@ typedef int (*conv_fn)(const void*, int, const void*, const void*, const void*, 
                        void*, int, int, int, int, int, void*);
 typedef int (*dw_fn)(const void*, int, const void*, void*, int, int, int, int, void*);
 typedef int (*tl_fn)(void*);
+typedef int (*dwhook_fn)(const void*, const void*, int);
 typedef const char* (*err_fn)(void);
 
 struct Lib {
@@ -51,6 +52,7 @@ struct Lib {
     dw_fn dw = nullptr;
     tl_fn tl = nullptr;
     tl_fn ns_tl = nullptr;
+    dwhook_fn dw_hook = nullptr;   // round 6: dcvc_dcb_nsplit_dw_hook
     err_fn err = nullptr;
     std::vector<float> us_core, us_core_next, us_seq, us_dw, us_ns, us_ns_next;
 };
@@ -83,6 +85,7 @@ static float median(std::vector<float> v)
 int main(int argc, char** argv)
 {
     int P = 32640, rounds = 5, n = 20, H = 136, W = 240, C = 384, CI = 0;
+    bool dw_inside = false;        // -w: the block launches take their depthwise conv inside (shapes that have the variant)
     std::vector<Lib> libs;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-p") && i + 1 < argc) { P = atoi(argv[++i]); H = 1; W = P; }
@@ -90,6 +93,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "-n") && i + 1 < argc) n = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-c") && i + 1 < argc) C = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-i") && i + 1 < argc) CI = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-w")) dw_inside = true;
+        else if (!strcmp(argv[i], "-g") && i + 2 < argc) { H = atoi(argv[++i]); W = atoi(argv[++i]); P = H * W; }
         else { Lib l; l.path = argv[i]; libs.push_back(l); }
     }
     if (CI == 0) CI = C;
@@ -106,6 +111,7 @@ int main(int argc, char** argv)
         l.dw = reinterpret_cast<dw_fn>(dlsym(l.h, "dcvc_dwconv3x3"));
         l.tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_core_timeline_buffer"));
         l.ns_tl = reinterpret_cast<tl_fn>(dlsym(l.h, "dcvc_dcb_nsplit_timeline_buffer"));
+        l.dw_hook = reinterpret_cast<dwhook_fn>(dlsym(l.h, "dcvc_dcb_nsplit_dw_hook"));
         l.err = reinterpret_cast<err_fn>(dlsym(l.h, "dcvc_last_error"));
         if (!l.conv || !l.err) { fprintf(stderr, "%s: missing symbols\n", l.path.c_str()); return 1; }      // (dcvc_dcb_core: libraries up to round 4 only)
     }
@@ -140,6 +146,13 @@ int main(int argc, char** argv)
         l.has_core = core_shape && l.core != nullptr && l.core(t2, C, x, C, w3, b3, w0, b0, w2, b2, nullptr, nullptr, nullptr, nullptr, nullptr, C, y, C, P, C, 0, st) >= 0;
     }
     OK(hipStreamSynchronize(st));
+    if (dw_inside) {
+        for (auto& l : libs) {
+            if (!l.dw_hook || H <= 1) { fprintf(stderr, "%s: -w needs dcvc_dcb_nsplit_dw_hook and a picture (no -p)\n", l.path.c_str()); return 1; }
+            chk(l, l.dw_hook(t2, wd, W), "dcb_nsplit_dw_hook");
+            printf("(-w: dcb_nsplit runs with its depthwise conv inside, on t2 as dc.0's output: its results differ from the reference line's by construction)\n");
+        }
+    }
     auto nsplit = [&](Lib& l, bool next) {
         if (l.ns_pack && l.ns_packed) {
             if (!l.ns_handle) chk(l, l.ns_pack(w3, w0, w2, w1, C, CI, st, &l.ns_handle), "dcb_nsplit_pack");
