@@ -720,7 +720,7 @@ def roofline(work, n=len(QPS)):
             # one entry per shape of the N-split block kernel: <C, CI, pixels per workgroup> follows from (N, K, M): K = 7 CI
             # with the next block's dc.0 inside the launch, 6 CI without (dcb_nsplit_kernel.h launch())
             var = buf["variant"].astype(np.int64)
-            if f == 5:       # the 8-wave kernel records its inner width and its NEXT slot (0, 1 = next dc.0, NN = closing conv)
+            if f == 5:       # the 8-wave kernel records its inner width, its NEXT slot (0, 1 = next dc.0, NN = closing conv) and, in bit 24, whether the depthwise conv ran inside
                 ci_of, slot = var & 0xFFF, (var >> 12) & 0xFFF
             else:
                 inner = {k * ci: ci for ci in (128, 256, 384, 512, 768) for k in (6, 7)}
@@ -741,6 +741,8 @@ def roofline(work, n=len(QPS)):
                     k["pixels"] = m
                     k["with_next_dc0"] = nxt
                     k["with_closing_conv"] = fin
+                    if f == 5:
+                        k["with_depthwise_inside"] = float(((var[one] >> 24) & 1).mean())      # round 6: the block's depthwise conv inside the launch
                     kernels.append(k)
             continue
         k = part(sel, name, None)

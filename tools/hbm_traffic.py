@@ -13,9 +13,10 @@ from collections import defaultdict
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 FAMILIES = ("conv_gemm_kernel", "dwconv3x3", "dcb_tail_kernel", "ffn_fused_kernel", "dcb_pair8_kernel")
-# (the last template argument - what the NEXT slot holds - was a bool until round 5 and is an int since round 6)
-NSPLIT = re.compile(r"dcb_nsplit(8?)_kernel<(\d+), (\d+), (\d+), (true|false|\d+)>")
-NSPLIT_MANGLED = re.compile(r"dcb_nsplit(8?)_kernelILi(\d+)ELi(\d+)ELi(\d+)EL[bi](\d+)E")
+# (the fourth template argument - what the NEXT slot holds - was a bool until round 5 and is an int since round 6; a fifth - the depthwise
+# conv inside the launch - came with round 6's last session)
+NSPLIT = re.compile(r"dcb_nsplit(8?)_kernel<(\d+), (\d+), (\d+), (true|false|\d+)(?:, \d+)?>")
+NSPLIT_MANGLED = re.compile(r"dcb_nsplit(8?)_kernelILi(\d+)ELi(\d+)ELi(\d+)EL[bi](\d+)E(?:Li\d+E)?")
 
 
 def family(name):

@@ -5,4 +5,4 @@ for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_ACTIV
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc7/$n -o c -- $R/tools/_bin/core_bench -r 2 -n 10 $R/dcvc_amd/libdcvc_amd.so > /tmp/pmc7_$n.log 2>&1 || echo "set failed: $set"
 done
 cd $R
-python tools/pmc_summary.py /tmp/pmc7 2>/dev/null | grep -i "nsplit8_kernel<384, 384, 2, 1>\|^==" | cut -c1-300
+python tools/pmc_summary.py /tmp/pmc7 2>/dev/null | grep -i "nsplit8_kernel<384, 384, 2, 1\|^==" | cut -c1-300

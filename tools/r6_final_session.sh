@@ -54,3 +54,29 @@ for w in ld intra hts htl; do
 done
 # round 6 against round 5's library on this box (tools/_bin/r05.so, when it travelled with the tree)
 if [ -f tools/_bin/r05.so ]; then bash tools/r6_ab_round.sh 2>/dev/null | grep "^pass" > $O/r06_round_ab_closing.txt; cat $O/r06_round_ab_closing.txt; fi
+# round 6, last session: the depthwise conv inside the (256, 128) / (384, 192) block launches - the LD codec with and without on this box
+# (fps, kernel trace), the launch under core_bench with its in-kernel stamps, the issue-rate probe behind its arithmetic
+B2="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-uhd --no-extras --no-roofline --no-pipeline --no-resolutions --min-seconds 0"
+for pass in 1 2 3; do for g in 0 1; do
+  DCVC_NSPLIT_DW=$g timeout 300 $B2 --workload ld 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('pass $pass ld 1920x1080 depthwise_inside=$g', round(d['value'],1), 'enc', round(d['encode_fps'],1), 'dec', round(d['decode_fps'],1))"
+done; done > $O/r06_dw_ab.txt
+for g in 0 1; do
+  DCVC_NSPLIT_DW=$g timeout 300 $B2 --workload ld --resolution 3840x2160 --steps 30 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('ld 3840x2160 depthwise_inside=$g', round(d['value'],1), 'enc', round(d['encode_fps'],1), 'dec', round(d['decode_fps'],1))"
+done >> $O/r06_dw_ab.txt
+cat $O/r06_dw_ab.txt
+cd /tmp
+DCVC_NSPLIT_DW=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof6_ld_dw0 -o t -- python $R/bench.py --workload ld --steps 10 --warmup 3 --no-cpu-baseline --no-uhd --no-resolutions --no-extras --no-roofline --no-pipeline --min-seconds 0 > $O/r06_prof_ld_dw0.log 2>&1
+python $R/tools/trace_after_setup.py /tmp/prof6_ld_dw0 --marker mask_step_enc --per 2 > $O/r06_ld_per_picture_dw0.txt 2>&1
+for g in 0 1; do
+  DCVC_NSPLIT_DW=$g timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof6_ld4k_$g -o t -- python $R/bench.py --workload ld --resolution 3840x2160 --steps 6 --warmup 2 --no-cpu-baseline --no-uhd --no-resolutions --no-extras --no-roofline --no-pipeline --min-seconds 0 > $O/r06_prof_ld4k_$g.log 2>&1
+  python $R/tools/trace_after_setup.py /tmp/prof6_ld4k_$g --marker mask_step_enc --per 2 > $O/r06_ld4k_per_picture_dw$g.txt 2>&1
+done
+cd $R
+bash tools/r6_dw_timeline.sh 2>&1 | cut -c1-1200 > $O/r06_dw_timeline.txt
+timeout 60 $B/fma_rate > $O/r06_fma_rate.txt 2>&1
