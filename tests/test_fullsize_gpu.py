@@ -213,14 +213,15 @@ def test_inter_matches_oracle_digest(name):
     # every DepthConvBlock as its launch sequence dc.0 | depthwise | dc.3 | ffn.0 | ffn.2 through conv_gemm
     ("DCVC_NO_DCB_CORE", "dmci_1920x1080_q32_t0.15 or dmci_1920x1080_q63_t0.0 or dmci_1280x720_q0_t0.15 or dmci_256x256 or "
                          "ld_1280x720 or hts_1280x720 or htl_1280x720", 7),
-    # round 6's launch fusions off: the convs that close a chain and the adaptor + dc.0 pairs as launches of their own again
+    # round 6's launch fusions off: the convs that close a chain, the adaptor + dc.0 pairs and the narrow blocks' depthwise convs as launches of their own again
     ("DCVC_NSPLIT_FIN", "dmci_1280x720_q32_t0.15 or ld_1280x720 or hts_1280x720 or htl_1280x720", 4),
     # no N-split kernel at all: dcb_tail / ffn_fused for the half-width blocks, the launch sequence for the full-width ones
     ("DCVC_NSPLIT", "dmci_256x256 or ld_1280x720", 2),
 ])
 def test_other_kernel_paths_match_the_digests(switch, pick, count):
     """The same digests with the block kernels switched off (DCVC_NO_DCB_CORE=1), with round 6's launch fusions off
-    (DCVC_NSPLIT_FIN=0 DCVC_PAIR=0: closing convs and adaptor + dc.0 pairs as separate launches) and with round 2's kernels
+    (DCVC_NSPLIT_FIN=0 DCVC_PAIR=0 DCVC_NSPLIT_DW=0: closing convs, adaptor + dc.0 pairs and the depthwise convs of LD's narrow blocks as
+    separate launches) and with round 2's kernels
     (DCVC_NSPLIT=0): all paths are the same arithmetic, operation for operation. The switches are read once per process,
     hence the child process. (Rounds 4 and 5 also ran round 3's 4-wave block kernel here; it was retired in round 6.)"""
     import subprocess
@@ -231,7 +232,7 @@ def test_other_kernel_paths_match_the_digests(switch, pick, count):
     if switch == "DCVC_NO_DCB_CORE":
         env.update(DCVC_NO_DCB_CORE="1", DCVC_DCB_TAIL="0", DCVC_FFN_FUSED="0")     # no fused block kernel of any kind
     elif switch == "DCVC_NSPLIT_FIN":
-        env.update(DCVC_NSPLIT_FIN="0", DCVC_PAIR="0")
+        env.update(DCVC_NSPLIT_FIN="0", DCVC_PAIR="0", DCVC_NSPLIT_DW="0")
     else:
         env[switch] = "0"
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
