@@ -73,7 +73,7 @@ struct Scratch {
     half_t* t3 = nullptr;
     size_t elems = 0;       // capacity of each plane in fp16 elements
     // which of t1 / t2 holds dc.0's output: a block launch with its depthwise conv inside reads it from one plane and leaves the
-    // NEXT block's in the other (DcbW::forward flips this; every chain starts by writing dc.0's output, so any state is a valid start)
+    // NEXT block's in the other (DcbW::forward flips this with every such hand-over and resets it whenever a block computes its own dc.0)
     mutable int hand = 0;
 };
 

@@ -226,6 +226,9 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
         throw std::runtime_error("DepthConvBlock: scratch planes too small");
     }
     View in = x;
+    // a block that computes its own dc.0 starts from the canonical planes: which plane a launch reads and writes is then a function of
+    // the chain's structure alone (launch sequences captured into graphs at different times agree with each other)
+    if (!dc0_done) s.hand = 0;
     half_t* const p1 = s.hand != 0 ? s.t2 : s.t1;      // dc.0's output (ours, or handed over by the previous launch)
     half_t* const p2 = s.hand != 0 ? s.t1 : s.t2;      // the depthwise conv's output / the next block's dc.0 output
     if (has_adaptor && shortcut) {
