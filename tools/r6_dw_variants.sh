@@ -1,4 +1,6 @@
-# Round 6: where the cost of the depthwise conv inside the block launch sits - timing variants (wrong results) under the LD trace
+# Round 6: where the cost of the depthwise conv inside the block launch sits - timing variants (wrong results) under the LD trace.
+# (The switches it was run with - build_variant.sh dw_nodma -DNS8_DW_NO_DMA, dw_nocomp -DNS8_DW_NO_COMPUTE, dw_none with both - were in the
+# kernel for that session only (git history: the commit before "tiles in XCD bands"); the result is profiles/r06_dw_variants.txt.)
 R=$(pwd); O=$R/gpurun_out/r06dw; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for v in "" dw_nodma dw_nocomp dw_none; do
