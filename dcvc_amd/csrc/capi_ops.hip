@@ -286,6 +286,7 @@ int dcvc_dcb_nsplit_dw(const void* t1, int ldt, const void* wdw, int width, cons
         if (!t1 || !wdw || !w3 || !w0 || !w2) throw std::invalid_argument("dcb_nsplit_dw: missing operand");
         if (!dcvc::dcb_nsplit_dw_supported(c, ci, pixels)) throw std::invalid_argument("dcb_nsplit_dw: no kernel variant with the depthwise conv inside for this block shape");
         if (wfin != nullptr && !dcvc::dcb_nsplit_fin_supported(c, ci, nfin)) throw std::invalid_argument("dcb_nsplit_dw: no kernel variant for this closing conv");
+        if (static_cast<long long>(pixels) * ldt * 2 >= (1LL << 31)) throw std::invalid_argument("dcb_nsplit_dw: dc.0's output must span less than 2 GiB (32-bit byte offsets inside the launch)");
         hipStream_t st = S(stream);
         const AsyncBuf wmain(dcvc::dcb_nsplit_main_halves(c, ci) * 2, st);
         dcvc::dcb_nsplit_pack_main(H(w3), H(w0), H(w2), c, ci, wmain.half(), st);

@@ -280,7 +280,8 @@ void DcbW::forward(View x, View y, int H, int W, const Scratch& s, hipStream_t s
     }
     // the narrow blocks take their depthwise conv into the block launch (dcb_nsplit8_kernel.h, DW): dc.0's output is read from one
     // scratch plane, the next block's written to the other
-    const bool dw_inside = nsplit() && dcb_nsplit_dw_supported(c, cdc, P);
+    // (the kernel addresses dc.0's output with 32-bit byte offsets from its base)
+    const bool dw_inside = nsplit() && dcb_nsplit_dw_supported(c, cdc, P) && static_cast<long long>(P) * cdc * 2 < (1LL << 31);
     if (!dw_inside) dwconv3x3(p1, cdc, dw, p2, cdc, H, W, cdc, st);
     if (nsplit()) {
         // [depthwise +] dc.3 + ffn.0 + ffn.2 (+ the next block's dc.0) in one launch, activations in LDS, weights per wave from L2
